@@ -1,0 +1,113 @@
+"""In-tree build recipes (hipcc / g++), no JIT cache: the built files travel to
+the GPU box with the repository snapshot.
+
+    python -m cuking_amd.build            # library + CLI
+    python -m cuking_amd.build --lib      # libcuking_amd.so only
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+CSRC = PKG / "csrc"
+HOST = PKG / "host"
+INCLUDE = ROOT / "include"
+
+LIB_PATH = PKG / "libcuking_amd.so"
+CLI_PATH = PKG / "bin" / "cuking"
+
+HIP_SOURCES = ["king_abi.hip", "king_kernels.hip", "synth.hip"]
+# IEEE-correct fp32 divide (kinship must match the reference bit for bit):
+# no fast-math, no contraction, correctly rounded divide/sqrt stays on.
+HIP_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
+    "-fno-fast-math", "-ffp-contract=off",
+    "-fhip-fp32-correctly-rounded-divide-sqrt",
+]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP library cannot be built")
+    return exe
+
+
+def _newer(target: Path, deps) -> bool:
+    if not target.exists():
+        return False
+    t = target.stat().st_mtime
+    return all(Path(d).stat().st_mtime <= t for d in deps)
+
+
+def build_library(force: bool = False, save_temps: bool = False) -> Path:
+    srcs = [CSRC / s for s in HIP_SOURCES]
+    deps = srcs + [CSRC / "king_common.h", INCLUDE / "cuking_amd.h",
+                   Path(__file__)]
+    if not force and _newer(LIB_PATH, deps):
+        return LIB_PATH
+    cmd = [_hipcc(), *HIP_FLAGS, "-shared", f"-I{INCLUDE}", f"-I{CSRC}",
+           *map(str, srcs), "-o", str(LIB_PATH)]
+    if save_temps:
+        tmp = PKG / "build_tmp"
+        tmp.mkdir(exist_ok=True)
+        cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+    subprocess.run(cmd, check=True, cwd=str(PKG))
+    return LIB_PATH
+
+
+def arrow_flags():
+    """Arrow/Parquet C++ headers and libraries bundled with the pyarrow wheel
+    (the reference links Arrow 8.0.0, Dockerfile:116)."""
+    import pyarrow
+    inc = pyarrow.get_include()
+    libdir = pyarrow.get_library_dirs()[0]
+    libs = []
+    for stem in ("parquet", "arrow"):
+        cands = sorted(Path(libdir).glob(f"lib{stem}.so.*"))
+        if not cands:
+            raise RuntimeError(f"lib{stem}.so not found in {libdir}")
+        libs.append(f"-l:{cands[0].name}")
+    return inc, libdir, libs
+
+
+def build_cli(force: bool = False) -> Path:
+    srcs = sorted(HOST.glob("*.cc"))
+    if not srcs:
+        raise RuntimeError("no host sources")
+    deps = srcs + sorted(HOST.glob("*.h")) + [INCLUDE / "cuking_amd.h",
+                                              LIB_PATH, Path(__file__)]
+    if not force and _newer(CLI_PATH, deps):
+        return CLI_PATH
+    inc, libdir, libs = arrow_flags()
+    CLI_PATH.parent.mkdir(exist_ok=True)
+    cmd = ["g++", "-O2", "-std=c++20", "-Wall", "-pthread",
+           f"-I{INCLUDE}", f"-I{HOST}", f"-isystem{inc}",
+           *map(str, srcs), "-o", str(CLI_PATH),
+           f"-L{PKG}", "-l:libcuking_amd.so", f"-L{libdir}", *libs,
+           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,$ORIGIN/..",
+           "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True)
+    return CLI_PATH
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", action="store_true", help="library only")
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--save-temps", action="store_true")
+    args = ap.parse_args(argv)
+    print(build_library(force=args.force, save_temps=args.save_temps))
+    if not args.lib:
+        print(build_cli(force=args.force))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,751 @@
+// C ABI of the KING hot path (include/cuking_amd.h): context, device memory,
+// layout preparation + kernel launch, timing hooks.  gfx950 only; no CPU
+// fallback -- every device entry point fails with CUKING_ERR_DEVICE when HIP
+// cannot provide a gfx950 device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "king_common.h"
+
+using namespace cuking;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+cuking_status fail(cuking_status code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                      \
+  do {                                                                     \
+    const hipError_t _e = (expr);                                          \
+    if (_e != hipSuccess) {                                                \
+      return fail(_e == hipErrorOutOfMemory ? CUKING_ERR_OUT_OF_MEMORY     \
+                                            : CUKING_ERR_DEVICE,           \
+                  "%s failed: %s", #expr, hipGetErrorString(_e));          \
+    }                                                                      \
+  } while (0)
+
+uint32_t ceil_div(uint32_t a, uint32_t b) {
+  return (uint32_t)(((uint64_t)a + b - 1) / b);
+}
+uint32_t round_up(uint32_t a, uint32_t b) { return ceil_div(a, b) * b; }
+
+struct EventPair {
+  hipEvent_t start = nullptr, stop = nullptr;
+};
+
+struct Timer {
+  std::vector<EventPair> pool;
+  size_t used = 0;
+
+  hipError_t begin(hipStream_t s, EventPair **out) {
+    if (used == pool.size()) {
+      EventPair p;
+      hipError_t e = hipEventCreate(&p.start);
+      if (e != hipSuccess) return e;
+      e = hipEventCreate(&p.stop);
+      if (e != hipSuccess) return e;
+      pool.push_back(p);
+    }
+    *out = &pool[used++];
+    return hipEventRecord((*out)->start, s);
+  }
+  hipError_t collect(double *ms, uint64_t *n) {
+    *ms = 0;
+    *n = used;
+    for (size_t k = 0; k < used; ++k) {
+      hipError_t e = hipEventSynchronize(pool[k].stop);
+      if (e != hipSuccess) return e;
+      float t = 0;
+      e = hipEventElapsedTime(&t, pool[k].start, pool[k].stop);
+      if (e != hipSuccess) return e;
+      *ms += t;
+    }
+    return hipSuccess;
+  }
+  void destroy() {
+    for (auto &p : pool) {
+      if (p.start) (void)hipEventDestroy(p.start);
+      if (p.stop) (void)hipEventDestroy(p.stop);
+    }
+    pool.clear();
+    used = 0;
+  }
+};
+
+}  // namespace
+
+struct cuking_ctx {
+  int device = 0;
+  cuking_kernel kernel = CUKING_KERNEL_TILED;
+  int variant = 0;
+  uint32_t band_rows = 16;
+
+  // Workspace of the tiled kernel: the k-major planes and the band prefix.
+  uint4 *planes = nullptr;
+  size_t planes_bytes = 0;
+  uint64_t *band_prefix = nullptr;
+  size_t band_prefix_entries = 0;
+  TileSpace prefix_for = {0, 0, 0, 0};  // tile space the prefix was built for
+
+  bool timing = false;
+  Timer king_timer, prepare_timer;
+};
+
+namespace {
+
+int default_variant() {
+  if (const char *v = getenv("CUKING_AMD_VARIANT")) {
+    const int k = atoi(v);
+    if (k >= 0 && k < kNumTiledVariants) return k;
+  }
+  return 0;
+}
+
+cuking_status bind(cuking_ctx *ctx) {
+  if (ctx == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null context");
+  HIP_TRY(hipSetDevice(ctx->device));
+  return CUKING_OK;
+}
+
+PlaneGeometry make_geometry(const cuking_submatrix &sm,
+                            uint32_t words_per_sample,
+                            const TiledVariant &v) {
+  PlaneGeometry g;
+  g.num_rows = sm_num_rows(sm);
+  g.num_cols = sm_num_cols(sm);
+  g.diag = sm_is_diag(sm) ? 1u : 0u;
+  g.rows_padded = round_up(g.num_rows, v.tile);
+  g.cols_padded = round_up(g.num_cols, v.tile);
+  g.col_base = g.diag ? 0u : g.rows_padded;
+  g.s_stride = g.diag ? g.rows_padded : g.rows_padded + g.cols_padded;
+  g.k_words = round_up(words_per_sample, v.k_chunk);  // 2 x 32-bit per u64 / 2 planes
+  return g;
+}
+
+TileSpace make_tiles(const PlaneGeometry &g, const TiledVariant &v,
+                     uint32_t band_rows) {
+  TileSpace t;
+  t.tiles_r = g.rows_padded / v.tile;
+  t.tiles_c = g.cols_padded / v.tile;
+  t.band_rows = band_rows;
+  t.diag = g.diag;
+  return t;
+}
+
+uint64_t total_tiles(const TileSpace &t) {
+  uint64_t n = 0;
+  for (uint32_t b = 0; b < t.num_bands(); ++b) n += t.band_tiles(b);
+  return n;
+}
+
+cuking_status check_block(const cuking_submatrix *sm,
+                          uint32_t words_per_sample) {
+  if (sm == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null submatrix");
+  if (sm->i_end < sm->i_begin || sm->j_end < sm->j_begin)
+    return fail(CUKING_ERR_INVALID_ARGUMENT, "submatrix ranges are reversed");
+  if (!sm_is_diag(*sm) && sm->j_begin < sm->i_end && sm_num_rows(*sm) != 0 &&
+      sm_num_cols(*sm) != 0)
+    return fail(CUKING_ERR_INVALID_ARGUMENT,
+                "row and column ranges must be identical or disjoint with "
+                "rows first");
+  if (sm_is_diag(*sm) && sm->i_end != sm->j_end)
+    return fail(CUKING_ERR_INVALID_ARGUMENT,
+                "a diagonal block needs identical row and column ranges");
+  if (words_per_sample == 0 || (words_per_sample & 1))
+    return fail(CUKING_ERR_INVALID_ARGUMENT,
+                "words_per_sample must be a positive even number");
+  return CUKING_OK;
+}
+
+// Builds planes + band prefix for `sm` in the context workspace.
+cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
+                      uint32_t words_per_sample, const uint64_t *d_bit_sets,
+                      hipStream_t stream, PlaneGeometry *geo_out,
+                      TileSpace *tiles_out) {
+  const TiledVariant &v = tiled_variant(ctx->variant);
+  const PlaneGeometry geo = make_geometry(sm, words_per_sample, v);
+  const TileSpace tiles = make_tiles(geo, v, ctx->band_rows);
+  *geo_out = geo;
+  *tiles_out = tiles;
+
+  const size_t need = (size_t)geo.k_words * geo.s_stride * sizeof(uint4);
+  if (need > ctx->planes_bytes) {
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (ctx->planes) HIP_TRY(hipFree(ctx->planes));
+    ctx->planes = nullptr;
+    ctx->planes_bytes = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->planes), need));
+    ctx->planes_bytes = need;
+  }
+  const uint32_t nb = tiles.num_bands();
+  if ((size_t)nb + 1 > ctx->band_prefix_entries) {
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (ctx->band_prefix) HIP_TRY(hipFree(ctx->band_prefix));
+    ctx->band_prefix = nullptr;
+    ctx->band_prefix_entries = 0;
+    ctx->prefix_for = TileSpace{0, 0, 0, 0};
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->band_prefix),
+                      ((size_t)nb + 1) * sizeof(uint64_t)));
+    ctx->band_prefix_entries = (size_t)nb + 1;
+  }
+  const TileSpace &pf = ctx->prefix_for;
+  if (pf.tiles_r != tiles.tiles_r || pf.tiles_c != tiles.tiles_c ||
+      pf.band_rows != tiles.band_rows || pf.diag != tiles.diag) {
+    std::vector<uint64_t> prefix((size_t)nb + 1, 0);
+    for (uint32_t b = 0; b < nb; ++b)
+      prefix[b + 1] = prefix[b] + tiles.band_tiles(b);
+    // Small and pageable: wait until the host buffer may go away.
+    HIP_TRY(hipMemcpyAsync(ctx->band_prefix, prefix.data(),
+                           prefix.size() * sizeof(uint64_t),
+                           hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    ctx->prefix_for = tiles;
+  }
+
+  if (need == 0) return CUKING_OK;
+  EventPair *ev = nullptr;
+  if (ctx->timing) HIP_TRY(ctx->prepare_timer.begin(stream, &ev));
+  HIP_TRY(launch_prepare_planes(d_bit_sets, words_per_sample, geo, ctx->planes,
+                                stream));
+  if (ev) HIP_TRY(hipEventRecord(ev->stop, stream));
+  return CUKING_OK;
+}
+
+cuking_status run_tiled(cuking_ctx *ctx, const cuking_submatrix &sm,
+                        uint32_t words_per_sample, const uint64_t *d_bit_sets,
+                        uint64_t tile_begin, uint64_t tile_end, bool whole,
+                        float kin_threshold, uint32_t max_results,
+                        cuking_result *d_results, uint32_t *d_result_index,
+                        uint32_t *d_result_overflow, cuking_counts *d_counts,
+                        hipStream_t stream) {
+  PlaneGeometry geo;
+  TileSpace tiles;
+  cuking_status st =
+      prepare(ctx, sm, words_per_sample, d_bit_sets, stream, &geo, &tiles);
+  if (st != CUKING_OK) return st;
+  const uint64_t n_tiles = total_tiles(tiles);
+  if (whole) {
+    tile_begin = 0;
+    tile_end = n_tiles;
+  }
+  if (tile_begin > tile_end || tile_end > n_tiles)
+    return fail(CUKING_ERR_INVALID_ARGUMENT,
+                "tile range [%llu, %llu) outside [0, %llu)",
+                (unsigned long long)tile_begin, (unsigned long long)tile_end,
+                (unsigned long long)n_tiles);
+  if (tile_begin == tile_end) return CUKING_OK;
+
+  TiledArgs a;
+  a.planes = ctx->planes;
+  a.geo = geo;
+  a.tiles = tiles;
+  a.band_prefix = ctx->band_prefix;
+  a.tile_begin = tile_begin;
+  a.i_begin = sm.i_begin;
+  a.j_begin = sm.j_begin;
+  a.kin_threshold = kin_threshold;
+  a.max_results = max_results;
+  a.results = d_results;
+  a.result_index = d_result_index;
+  a.result_overflow = d_result_overflow;
+  a.dense_counts = d_counts;
+
+  EventPair *ev = nullptr;
+  if (ctx->timing) HIP_TRY(ctx->king_timer.begin(stream, &ev));
+  HIP_TRY(launch_tiled(ctx->variant, a, tile_end - tile_begin, stream));
+  if (ev) HIP_TRY(hipEventRecord(ev->stop, stream));
+  return CUKING_OK;
+}
+
+cuking_status run_stream(cuking_ctx *ctx, const cuking_submatrix &sm,
+                         uint32_t words_per_sample, const uint64_t *d_bit_sets,
+                         float kin_threshold, uint32_t max_results,
+                         cuking_result *d_results, uint32_t *d_result_index,
+                         uint32_t *d_result_overflow, cuking_counts *d_counts,
+                         hipStream_t stream) {
+  EventPair *ev = nullptr;
+  if (ctx->timing) HIP_TRY(ctx->king_timer.begin(stream, &ev));
+  HIP_TRY(launch_stream(sm, words_per_sample, d_bit_sets, kin_threshold,
+                        max_results, d_results, d_result_index,
+                        d_result_overflow, d_counts, stream));
+  if (ev) HIP_TRY(hipEventRecord(ev->stop, stream));
+  return CUKING_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *cuking_last_error(void) { return g_last_error.c_str(); }
+uint32_t cuking_abi_version(void) { return CUKING_ABI_VERSION; }
+
+// ---- host-only helpers ----------------------------------------------------
+
+cuking_status cuking_submatrix_init(cuking_submatrix *sm, uint32_t num_samples,
+                                    uint32_t split_factor,
+                                    uint32_t shard_index) {
+  if (sm == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null submatrix");
+  if (split_factor == 0)
+    return fail(CUKING_ERR_INVALID_ARGUMENT, "Invalid split factor");
+  const uint64_t shards = (uint64_t)split_factor * ((uint64_t)split_factor + 1) / 2;
+  if (shard_index >= shards)
+    return fail(CUKING_ERR_INVALID_ARGUMENT, "Invalid shard index");
+  // Row r of the block triangle starts at shard r*k - r(r-1)/2.
+  uint32_t block_i = 0;
+  uint64_t first = 0;
+  while (first + (split_factor - block_i) <= shard_index) {
+    first += split_factor - block_i;
+    ++block_i;
+  }
+  const uint32_t block_j = block_i + (uint32_t)(shard_index - first);
+  const uint64_t size = ceil_div(num_samples, split_factor);
+  auto clamp = [&](uint64_t x) {
+    return (uint32_t)std::min<uint64_t>(x, num_samples);
+  };
+  sm->i_begin = clamp(block_i * size);
+  sm->i_end = clamp(block_i * size + size);
+  sm->j_begin = clamp(block_j * size);
+  sm->j_end = clamp(block_j * size + size);
+  return CUKING_OK;
+}
+
+uint32_t cuking_submatrix_num_rows(const cuking_submatrix *sm) { return sm_num_rows(*sm); }
+uint32_t cuking_submatrix_num_cols(const cuking_submatrix *sm) { return sm_num_cols(*sm); }
+uint32_t cuking_submatrix_num_samples(const cuking_submatrix *sm) { return sm_num_samples(*sm); }
+uint32_t cuking_submatrix_contains(const cuking_submatrix *sm, uint32_t index) {
+  return sm_contains(*sm, index) ? 1u : 0u;
+}
+uint32_t cuking_submatrix_sample_offset(const cuking_submatrix *sm, uint32_t index) {
+  return sm_sample_offset(*sm, index);
+}
+
+uint64_t cuking_submatrix_num_pairs(const cuking_submatrix *sm) {
+  const uint64_t r = sm_num_rows(*sm), c = sm_num_cols(*sm);
+  if (sm_is_diag(*sm)) return r * (r - (r ? 1 : 0)) / 2;
+  // Off-diagonal blocks lie strictly above the diagonal: every (i, j) counts.
+  uint64_t n = 0;
+  if (sm->j_begin >= sm->i_end) return r * c;
+  for (uint32_t i = sm->i_begin; i < sm->i_end; ++i) {
+    const uint32_t lo = std::max(sm->j_begin, i + 1);
+    if (lo < sm->j_end) n += sm->j_end - lo;
+  }
+  return n;
+}
+
+uint32_t cuking_padded_sites(uint32_t num_sites) { return round_up(num_sites, 32u); }
+uint32_t cuking_words_per_sample(uint32_t num_sites) {
+  return 2u * ceil_div(cuking_padded_sites(num_sites), 64u);
+}
+uint64_t cuking_bytes_per_pair(uint32_t words_per_sample) {
+  return 2ull * words_per_sample * sizeof(uint64_t);
+}
+
+cuking_status cuking_pack_host(const cuking_submatrix *sm,
+                               uint32_t words_per_sample, uint64_t *bit_set,
+                               const int64_t *row_idx, const int64_t *col_idx,
+                               const int32_t *n_alt_alleles,
+                               size_t num_triples) {
+  cuking_status st = check_block(sm, words_per_sample);
+  if (st != CUKING_OK) return st;
+  const uint32_t plane_words = words_per_sample / 2;
+  const uint64_t plane_bits = (uint64_t)plane_words * 64;
+  auto clear_bit = [](uint64_t *plane, uint64_t index) {
+    __atomic_and_fetch(plane + (index >> 6), ~(1ull << (index & 63)),
+                       __ATOMIC_RELAXED);
+  };
+  for (size_t t = 0; t < num_triples; ++t) {
+    const int64_t col = col_idx[t];
+    if (col < 0 || col > 0xFFFFFFFFll || !sm_contains(*sm, (uint32_t)col))
+      continue;
+    const int64_t row = row_idx[t];
+    if (row < 0 || (uint64_t)row >= plane_bits)
+      return fail(CUKING_ERR_INVALID_ARGUMENT,
+                  "row_idx %lld outside the %llu padded sites", (long long)row,
+                  (unsigned long long)plane_bits);
+    uint64_t *het = bit_set + (uint64_t)sm_sample_offset(*sm, (uint32_t)col) *
+                                  words_per_sample;
+    uint64_t *hom = het + plane_words;
+    switch (n_alt_alleles[t]) {
+      case 0:
+        clear_bit(het, (uint64_t)row);
+        clear_bit(hom, (uint64_t)row);
+        break;
+      case 1:
+        clear_bit(hom, (uint64_t)row);
+        break;
+      case 2:
+        clear_bit(het, (uint64_t)row);
+        break;
+      default:
+        return fail(CUKING_ERR_FAILED_PRECONDITION,
+                    "Invalid value for n_alt_alleles (%d) encountered",
+                    n_alt_alleles[t]);
+    }
+  }
+  return CUKING_OK;
+}
+
+void cuking_sort_results(cuking_result *results, size_t num_results) {
+  std::sort(results, results + num_results,
+            [](const cuking_result &a, const cuking_result &b) {
+              return std::tie(a.sample_i, a.sample_j, a.kin) <
+                     std::tie(b.sample_i, b.sample_j, b.kin);
+            });
+}
+
+// ---- context and memory ---------------------------------------------------
+
+int cuking_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+cuking_status cuking_ctx_create(int device, cuking_ctx **out) {
+  if (out == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null out pointer");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0)
+    return fail(CUKING_ERR_DEVICE,
+                "no HIP device available (%s); this library has no CPU path",
+                e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+  if (device < 0 || device >= n)
+    return fail(CUKING_ERR_INVALID_ARGUMENT, "device %d outside [0, %d)", device, n);
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(CUKING_ERR_DEVICE,
+                "device %d is %s; this library only carries gfx950 code",
+                device, prop.gcnArchName);
+  HIP_TRY(hipSetDevice(device));
+  cuking_ctx *ctx = new cuking_ctx();
+  ctx->device = device;
+  ctx->variant = default_variant();
+  if (const char *v = getenv("CUKING_AMD_BAND_ROWS")) {
+    const int k = atoi(v);
+    if (k >= 1 && k <= 64) ctx->band_rows = (uint32_t)k;
+  }
+  *out = ctx;
+  return CUKING_OK;
+}
+
+void cuking_ctx_destroy(cuking_ctx *ctx) {
+  if (ctx == nullptr) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->planes) (void)hipFree(ctx->planes);
+  if (ctx->band_prefix) (void)hipFree(ctx->band_prefix);
+  ctx->king_timer.destroy();
+  ctx->prepare_timer.destroy();
+  delete ctx;
+}
+
+cuking_status cuking_ctx_set_kernel(cuking_ctx *ctx, cuking_kernel kernel) {
+  if (ctx == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null context");
+  if (kernel != CUKING_KERNEL_TILED && kernel != CUKING_KERNEL_STREAM)
+    return fail(CUKING_ERR_INVALID_ARGUMENT, "unknown kernel %d", (int)kernel);
+  ctx->kernel = kernel;
+  return CUKING_OK;
+}
+
+cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
+                                    int64_t value) {
+  if (ctx == nullptr || key == nullptr)
+    return fail(CUKING_ERR_INVALID_ARGUMENT, "null argument");
+  if (strcmp(key, "variant") == 0) {
+    if (value < 0 || value >= kNumTiledVariants)
+      return fail(CUKING_ERR_INVALID_ARGUMENT, "variant outside [0, %d)",
+                  kNumTiledVariants);
+    ctx->variant = (int)value;
+    return CUKING_OK;
+  }
+  if (strcmp(key, "band_rows") == 0) {
+    if (value < 1 || value > 64)
+      return fail(CUKING_ERR_INVALID_ARGUMENT, "band_rows outside [1, 64]");
+    ctx->band_rows = (uint32_t)value;
+    return CUKING_OK;
+  }
+  return fail(CUKING_ERR_INVALID_ARGUMENT, "unknown option %s", key);
+}
+
+cuking_status cuking_device_alloc(cuking_ctx *ctx, size_t bytes, void **d_ptr) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  if (d_ptr == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null out pointer");
+  *d_ptr = nullptr;
+  if (bytes == 0) return CUKING_OK;
+  HIP_TRY(hipMalloc(d_ptr, bytes));
+  return CUKING_OK;
+}
+
+cuking_status cuking_device_free(cuking_ctx *ctx, void *d_ptr) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  if (d_ptr) HIP_TRY(hipFree(d_ptr));
+  return CUKING_OK;
+}
+
+cuking_status cuking_memset_async(cuking_ctx *ctx, void *d_ptr, int byte_value,
+                                  size_t bytes, void *stream) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  if (bytes) HIP_TRY(hipMemsetAsync(d_ptr, byte_value, bytes, (hipStream_t)stream));
+  return CUKING_OK;
+}
+
+cuking_status cuking_copy_to_device(cuking_ctx *ctx, void *d_dst,
+                                    const void *src, size_t bytes,
+                                    void *stream) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  if (bytes)
+    HIP_TRY(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice,
+                           (hipStream_t)stream));
+  return CUKING_OK;
+}
+
+cuking_status cuking_copy_to_host(cuking_ctx *ctx, void *dst, const void *d_src,
+                                  size_t bytes, void *stream) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  if (bytes)
+    HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost,
+                           (hipStream_t)stream));
+  return CUKING_OK;
+}
+
+cuking_status cuking_stream_synchronize(cuking_ctx *ctx, void *stream) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return CUKING_OK;
+}
+
+cuking_status cuking_host_alloc(cuking_ctx *ctx, size_t bytes, void **ptr) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  if (ptr == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null out pointer");
+  *ptr = nullptr;
+  if (bytes == 0) return CUKING_OK;
+  HIP_TRY(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+  return CUKING_OK;
+}
+
+cuking_status cuking_host_free(cuking_ctx *ctx, void *ptr) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  if (ptr) HIP_TRY(hipHostFree(ptr));
+  return CUKING_OK;
+}
+
+// ---- hot path -------------------------------------------------------------
+
+cuking_status cuking_pack_device(cuking_ctx *ctx, const cuking_submatrix *sm,
+                                 uint32_t words_per_sample, uint64_t *d_bit_set,
+                                 const int64_t *d_row_idx,
+                                 const int64_t *d_col_idx,
+                                 const int32_t *d_n_alt_alleles,
+                                 size_t num_triples, uint32_t *d_status,
+                                 void *stream) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  st = check_block(sm, words_per_sample);
+  if (st != CUKING_OK) return st;
+  if (num_triples &&
+      (!d_bit_set || !d_row_idx || !d_col_idx || !d_n_alt_alleles || !d_status))
+    return fail(CUKING_ERR_INVALID_ARGUMENT, "null device pointer");
+  HIP_TRY(launch_pack(*sm, words_per_sample, d_bit_set, d_row_idx, d_col_idx,
+                      d_n_alt_alleles, num_triples, d_status,
+                      (hipStream_t)stream));
+  return CUKING_OK;
+}
+
+uint32_t cuking_tile_samples(const cuking_ctx *ctx) {
+  return tiled_variant(ctx ? ctx->variant : default_variant()).tile;
+}
+
+uint64_t cuking_num_tiles(const cuking_ctx *ctx, const cuking_submatrix *sm) {
+  if (sm == nullptr) return 0;
+  const TiledVariant &v = tiled_variant(ctx ? ctx->variant : default_variant());
+  const PlaneGeometry g = make_geometry(*sm, 2, v);
+  if (g.num_rows == 0 || g.num_cols == 0) return 0;
+  return total_tiles(make_tiles(g, v, ctx ? ctx->band_rows : 16));
+}
+
+cuking_status cuking_tile_bounds(const cuking_ctx *ctx,
+                                 const cuking_submatrix *sm, uint64_t tile,
+                                 uint32_t *row_begin, uint32_t *row_end,
+                                 uint32_t *col_begin, uint32_t *col_end) {
+  cuking_status st = check_block(sm, 2);
+  if (st != CUKING_OK) return st;
+  const TiledVariant &v = tiled_variant(ctx ? ctx->variant : default_variant());
+  const PlaneGeometry g = make_geometry(*sm, 2, v);
+  const TileSpace ts = make_tiles(g, v, ctx ? ctx->band_rows : 16);
+  if (g.num_rows == 0 || g.num_cols == 0 || tile >= total_tiles(ts))
+    return fail(CUKING_ERR_INVALID_ARGUMENT, "tile index out of range");
+  uint32_t b = 0;
+  uint64_t first = 0;
+  while (first + ts.band_tiles(b) <= tile) first += ts.band_tiles(b++);
+  uint32_t tr, tc;
+  ts.decode(b, tile - first, &tr, &tc);
+  auto clampr = [&](uint64_t x) { return (uint32_t)std::min<uint64_t>(x, g.num_rows); };
+  auto clampc = [&](uint64_t x) { return (uint32_t)std::min<uint64_t>(x, g.num_cols); };
+  if (row_begin) *row_begin = sm->i_begin + clampr((uint64_t)tr * v.tile);
+  if (row_end) *row_end = sm->i_begin + clampr((uint64_t)(tr + 1) * v.tile);
+  if (col_begin) *col_begin = sm->j_begin + clampc((uint64_t)tc * v.tile);
+  if (col_end) *col_end = sm->j_begin + clampc((uint64_t)(tc + 1) * v.tile);
+  return CUKING_OK;
+}
+
+int cuking_num_variants(void) { return kNumTiledVariants; }
+const char *cuking_variant_name(int variant) {
+  if (variant < 0 || variant >= kNumTiledVariants) return "";
+  return tiled_variant(variant).name;
+}
+
+static cuking_status check_compute_args(const cuking_submatrix *sm,
+                                        uint32_t words_per_sample,
+                                        const uint64_t *d_bit_sets) {
+  cuking_status st = check_block(sm, words_per_sample);
+  if (st != CUKING_OK) return st;
+  if (sm_num_samples(*sm) != 0 && d_bit_sets == nullptr)
+    return fail(CUKING_ERR_INVALID_ARGUMENT, "null bitset pointer");
+  return CUKING_OK;
+}
+
+cuking_status cuking_compute_king(cuking_ctx *ctx, const cuking_submatrix *sm,
+                                  uint32_t words_per_sample,
+                                  const uint64_t *d_bit_sets,
+                                  float kin_threshold, uint32_t max_results,
+                                  cuking_result *d_results,
+                                  uint32_t *d_result_index,
+                                  uint32_t *d_result_overflow, void *stream) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  st = check_compute_args(sm, words_per_sample, d_bit_sets);
+  if (st != CUKING_OK) return st;
+  if (!d_result_index || !d_result_overflow || (max_results && !d_results))
+    return fail(CUKING_ERR_INVALID_ARGUMENT, "null result pointer");
+  if (sm_num_rows(*sm) == 0 || sm_num_cols(*sm) == 0) return CUKING_OK;
+  if (ctx->kernel == CUKING_KERNEL_STREAM)
+    return run_stream(ctx, *sm, words_per_sample, d_bit_sets, kin_threshold,
+                      max_results, d_results, d_result_index, d_result_overflow,
+                      nullptr, (hipStream_t)stream);
+  return run_tiled(ctx, *sm, words_per_sample, d_bit_sets, 0, 0, true,
+                   kin_threshold, max_results, d_results, d_result_index,
+                   d_result_overflow, nullptr, (hipStream_t)stream);
+}
+
+cuking_status cuking_compute_king_tiles(
+    cuking_ctx *ctx, const cuking_submatrix *sm, uint32_t words_per_sample,
+    const uint64_t *d_bit_sets, uint64_t tile_begin, uint64_t tile_end,
+    float kin_threshold, uint32_t max_results, cuking_result *d_results,
+    uint32_t *d_result_index, uint32_t *d_result_overflow, void *stream) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  st = check_compute_args(sm, words_per_sample, d_bit_sets);
+  if (st != CUKING_OK) return st;
+  if (!d_result_index || !d_result_overflow || (max_results && !d_results))
+    return fail(CUKING_ERR_INVALID_ARGUMENT, "null result pointer");
+  if (sm_num_rows(*sm) == 0 || sm_num_cols(*sm) == 0) {
+    if (tile_begin != 0 || tile_end != 0)
+      return fail(CUKING_ERR_INVALID_ARGUMENT, "empty block has no tiles");
+    return CUKING_OK;
+  }
+  return run_tiled(ctx, *sm, words_per_sample, d_bit_sets, tile_begin, tile_end,
+                   false, kin_threshold, max_results, d_results, d_result_index,
+                   d_result_overflow, nullptr, (hipStream_t)stream);
+}
+
+cuking_status cuking_compute_counts(cuking_ctx *ctx, const cuking_submatrix *sm,
+                                    uint32_t words_per_sample,
+                                    const uint64_t *d_bit_sets,
+                                    cuking_counts *d_counts, void *stream) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  st = check_compute_args(sm, words_per_sample, d_bit_sets);
+  if (st != CUKING_OK) return st;
+  if (sm_num_rows(*sm) == 0 || sm_num_cols(*sm) == 0) return CUKING_OK;
+  if (d_counts == nullptr)
+    return fail(CUKING_ERR_INVALID_ARGUMENT, "null counts pointer");
+  if (ctx->kernel == CUKING_KERNEL_STREAM)
+    return run_stream(ctx, *sm, words_per_sample, d_bit_sets, 0.f, 0, nullptr,
+                      nullptr, nullptr, d_counts, (hipStream_t)stream);
+  return run_tiled(ctx, *sm, words_per_sample, d_bit_sets, 0, 0, true, 0.f, 0,
+                   nullptr, nullptr, nullptr, d_counts, (hipStream_t)stream);
+}
+
+// ---- timing ---------------------------------------------------------------
+
+cuking_status cuking_timing_enable(cuking_ctx *ctx, int enabled) {
+  if (ctx == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null context");
+  ctx->timing = enabled != 0;
+  return CUKING_OK;
+}
+
+cuking_status cuking_timing_reset(cuking_ctx *ctx) {
+  if (ctx == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null context");
+  ctx->king_timer.used = 0;
+  ctx->prepare_timer.used = 0;
+  return CUKING_OK;
+}
+
+cuking_status cuking_timing_collect(cuking_ctx *ctx, double *king_ms,
+                                    uint64_t *king_launches, double *prepare_ms,
+                                    uint64_t *prepare_launches) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  double a = 0, b = 0;
+  uint64_t na = 0, nb = 0;
+  HIP_TRY(ctx->king_timer.collect(&a, &na));
+  HIP_TRY(ctx->prepare_timer.collect(&b, &nb));
+  if (king_ms) *king_ms = a;
+  if (king_launches) *king_launches = na;
+  if (prepare_ms) *prepare_ms = b;
+  if (prepare_launches) *prepare_launches = nb;
+  return CUKING_OK;
+}
+
+// ---- synthetic inputs -----------------------------------------------------
+
+cuking_status cuking_synth_bitset(cuking_ctx *ctx, uint64_t seed,
+                                  const uint32_t *d_kind, const uint32_t *d_pa,
+                                  const uint32_t *d_pb, uint32_t sample_begin,
+                                  uint32_t sample_end, uint32_t num_sites,
+                                  uint32_t words_per_sample,
+                                  uint64_t *d_bit_set, void *stream) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  if (sample_end < sample_begin)
+    return fail(CUKING_ERR_INVALID_ARGUMENT, "sample range reversed");
+  if (words_per_sample != cuking_words_per_sample(num_sites))
+    return fail(CUKING_ERR_INVALID_ARGUMENT,
+                "words_per_sample %u does not match %u sites", words_per_sample,
+                num_sites);
+  if (sample_end > sample_begin && (!d_kind || !d_pa || !d_pb || !d_bit_set))
+    return fail(CUKING_ERR_INVALID_ARGUMENT, "null device pointer");
+  HIP_TRY(launch_synth(seed, d_kind, d_pa, d_pb, sample_begin, sample_end,
+                       num_sites, words_per_sample, d_bit_set,
+                       (hipStream_t)stream));
+  return CUKING_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,165 @@
+// Shared host/device declarations of the KING hot path (gfx950 only).
+#ifndef CUKING_AMD_KING_COMMON_H_
+#define CUKING_AMD_KING_COMMON_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cuking_amd.h"
+
+namespace cuking {
+
+// ---------------------------------------------------------------------------
+// Plane layout (device-internal; built by prepare_planes from the reference
+// bitset of cuking.cu:507-523).
+//
+// For every 32-site word k and every stored sample s one uint4:
+//     x = H    het and defined            (het & ~hom_var)
+//     y = A    hom-alt                    (hom_var & ~het)
+//     z = Hom  hom-ref or hom-alt         (~het)
+//     w = D    defined (not missing)      ~(het & hom_var)
+// laid out k-major: planes[k * s_stride + s].  Row samples occupy
+// [0, rows_padded), column samples [col_base, col_base + cols_padded); for a
+// diagonal block col_base = 0 and the samples are stored once (cuking.cu:161).
+// Padding samples and padding k-words are all-zero (= everything missing),
+// so they add nothing to any sum.
+// ---------------------------------------------------------------------------
+struct PlaneGeometry {
+  uint32_t num_rows, num_cols;        // block shape in samples
+  uint32_t rows_padded, cols_padded;  // rounded up to the tile edge
+  uint32_t col_base;                  // plane index of column sample 0
+  uint32_t s_stride;                  // uint4 per k-row
+  uint32_t k_words;                   // 32-site words, padded to the K chunk
+  uint32_t diag;                      // rows and columns are the same samples
+};
+
+// Tiles of the block's pair space, enumerated band by band: a band is
+// `band_rows` tile-rows high and is walked column-major, so that workgroups
+// resident at the same time share few row/column strips (L2 reuse per XCD).
+// A diagonal block only has tiles with tile_row <= tile_col.
+struct TileSpace {
+  uint32_t tiles_r, tiles_c;
+  uint32_t band_rows;
+  uint32_t diag;
+
+  __host__ __device__ uint32_t num_bands() const {
+    return (tiles_r + band_rows - 1) / band_rows;
+  }
+  // Tiles in band b.
+  __host__ __device__ uint64_t band_tiles(uint32_t b) const {
+    const uint32_t r0 = b * band_rows;
+    const uint32_t h = (tiles_r - r0 < band_rows) ? tiles_r - r0 : band_rows;
+    if (!diag) return (uint64_t)h * tiles_c;
+    const uint32_t ncols = tiles_c - r0;  // columns r0 .. tiles_c-1
+    return (uint64_t)h * (h + 1) / 2 + (uint64_t)(ncols - h) * h;
+  }
+  // Decodes index u inside band b.
+  __host__ __device__ void decode(uint32_t b, uint64_t u, uint32_t *tr,
+                                  uint32_t *tc) const {
+    const uint32_t r0 = b * band_rows;
+    const uint32_t h = (tiles_r - r0 < band_rows) ? tiles_r - r0 : band_rows;
+    if (!diag) {
+      *tc = (uint32_t)(u / h);
+      *tr = r0 + (uint32_t)(u % h);
+      return;
+    }
+    const uint64_t tri = (uint64_t)h * (h + 1) / 2;
+    if (u < tri) {
+      // Column r0 + c holds c + 1 tiles (rows r0 .. r0 + c).
+      uint32_t c = 0;
+      uint64_t before = 0;
+      while (before + c + 1 <= u) {
+        before += c + 1;
+        ++c;
+      }
+      *tc = r0 + c;
+      *tr = r0 + (uint32_t)(u - before);
+    } else {
+      const uint64_t v = u - tri;
+      *tc = r0 + h + (uint32_t)(v / h);
+      *tr = r0 + (uint32_t)(v % h);
+    }
+  }
+};
+
+// Arguments of the tiled pair kernel.
+struct TiledArgs {
+  const uint4 *planes;
+  PlaneGeometry geo;
+  TileSpace tiles;
+  const uint64_t *band_prefix;  // device; num_bands + 1 entries
+  uint64_t tile_begin;          // first tile of this launch
+  uint32_t i_begin, j_begin;    // global sample index of row / column 0
+  float kin_threshold;
+  uint32_t max_results;
+  cuking_result *results;
+  uint32_t *result_index;
+  uint32_t *result_overflow;
+  cuking_counts *dense_counts;  // non-null: diagnostic mode, no threshold
+};
+
+// One compiled shape of the tiled kernel.
+struct TiledVariant {
+  const char *name;
+  uint32_t tile;      // samples per tile edge
+  uint32_t k_chunk;   // 32-site words staged per LDS buffer
+  uint32_t threads;   // workgroup size
+  uint32_t lds_bytes; // dynamic LDS
+};
+
+constexpr int kNumTiledVariants = 4;
+const TiledVariant &tiled_variant(int v);
+// Enqueues tiles [args.tile_begin, args.tile_begin + num_tiles).
+hipError_t launch_tiled(int variant, const TiledArgs &args, uint64_t num_tiles,
+                        hipStream_t stream);
+
+hipError_t launch_prepare_planes(const uint64_t *d_bit_sets,
+                                 uint32_t words_per_sample,
+                                 const PlaneGeometry &geo, uint4 *d_planes,
+                                 hipStream_t stream);
+
+hipError_t launch_stream(const cuking_submatrix &sm, uint32_t words_per_sample,
+                         const uint64_t *d_bit_sets, float kin_threshold,
+                         uint32_t max_results, cuking_result *d_results,
+                         uint32_t *d_result_index, uint32_t *d_result_overflow,
+                         cuking_counts *d_dense_counts, hipStream_t stream);
+
+hipError_t launch_pack(const cuking_submatrix &sm, uint32_t words_per_sample,
+                       uint64_t *d_bit_set, const int64_t *d_row_idx,
+                       const int64_t *d_col_idx, const int32_t *d_n_alt,
+                       size_t num_triples, uint32_t *d_status,
+                       hipStream_t stream);
+
+hipError_t launch_synth(uint64_t seed, const uint32_t *d_kind,
+                        const uint32_t *d_pa, const uint32_t *d_pb,
+                        uint32_t sample_begin, uint32_t sample_end,
+                        uint32_t num_sites, uint32_t words_per_sample,
+                        uint64_t *d_bit_set, hipStream_t stream);
+
+// Submatrix helpers usable on both sides (cuking.cu:154-175).
+__host__ __device__ inline uint32_t sm_num_rows(const cuking_submatrix &s) {
+  return s.i_end - s.i_begin;
+}
+__host__ __device__ inline uint32_t sm_num_cols(const cuking_submatrix &s) {
+  return s.j_end - s.j_begin;
+}
+__host__ __device__ inline bool sm_is_diag(const cuking_submatrix &s) {
+  return s.i_begin == s.j_begin;
+}
+__host__ __device__ inline uint32_t sm_num_samples(const cuking_submatrix &s) {
+  return sm_is_diag(s) ? sm_num_rows(s) : sm_num_rows(s) + sm_num_cols(s);
+}
+__host__ __device__ inline bool sm_contains(const cuking_submatrix &s,
+                                            uint32_t index) {
+  return (s.i_begin <= index && index < s.i_end) ||
+         (s.j_begin <= index && index < s.j_end);
+}
+__host__ __device__ inline uint32_t sm_sample_offset(const cuking_submatrix &s,
+                                                     uint32_t index) {
+  return index < s.i_end ? index - s.i_begin
+                         : (s.i_end - s.i_begin) + (index - s.j_begin);
+}
+
+}  // namespace cuking
+
+#endif  // CUKING_AMD_KING_COMMON_H_

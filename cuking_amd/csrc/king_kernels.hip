@@ -1,0 +1,484 @@
+// HIP kernels of the KING hot path, written for gfx950 (MI355X, wave64).
+//
+//   prepare_planes_kernel  reference bitset (cuking.cu:507-523) -> k-major
+//                          4-plane layout (king_common.h)
+//   king_tiled_kernel      the throughput kernel: LDS-staged, register-tiled
+//                          AND+popcount over all pairs of a tile
+//                          (replaces ComputeKingKernel, cuking.cu:191-314)
+//   king_stream_kernel     one pair per wavefront straight from the reference
+//                          layout, wave-level reductions (same contract)
+//   pack_kernel            cuking.cu:675-703 on the device
+//
+// No MFMA: the work is AND / BITOP3 / BCNT on 32-bit words (VALU) fed from
+// LDS; see DESIGN.md for the op count and the rooflines.
+#include <hip/hip_runtime.h>
+
+#include "king_common.h"
+
+namespace cuking {
+
+namespace {
+
+typedef __attribute__((address_space(3))) void *lds_void_ptr;
+typedef const __attribute__((address_space(1))) void *global_void_ptr;
+
+// cuking.cu:289-294: two float32 roundings (divide, add).  Numerator and
+// denominator are exact integers (< 2^24 for < 2^22 sites); the divide is the
+// IEEE-correct one (no fast-math, see build flags).  min == 0 gives -inf or
+// NaN, which fails `kin > threshold`.
+__device__ __forceinline__ float king_kinship(uint32_t het_i, uint32_t het_j,
+                                              uint32_t both_het,
+                                              uint32_t opposing_hom) {
+  const uint32_t min_hets = het_i < het_j ? het_i : het_j;
+  const float num = 2.f * (float)both_het - 4.f * (float)opposing_hom -
+                    (float)het_i - (float)het_j;
+  const float den = 4.f * (float)min_hets;
+  return 0.5f + num / den;
+}
+
+// cuking.cu:297-313: reserve a slot, store or flag overflow.
+__device__ __forceinline__ void emit_result(uint32_t i, uint32_t j, float kin,
+                                            uint32_t ibs0, uint32_t ibs1,
+                                            uint32_t ibs2, uint32_t max_results,
+                                            cuking_result *results,
+                                            uint32_t *result_index,
+                                            uint32_t *result_overflow) {
+  const uint32_t slot = atomicAdd(result_index, 1u);
+  if (slot < max_results) {
+    cuking_result r;
+    r.sample_i = i;
+    r.sample_j = j;
+    r.kin = kin;
+    r.ibs0 = ibs0;
+    r.ibs1 = ibs1;
+    r.ibs2 = ibs2;
+    results[slot] = r;
+  } else {
+    atomicMax(result_overflow, 1u);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// prepare_planes_kernel
+// One workgroup: 64 plane-samples x 16 source words (= 32 k-rows).  Reads are
+// coalesced along a sample's words, the transpose goes through LDS, writes are
+// coalesced along samples (1 KiB per k-row).
+// ---------------------------------------------------------------------------
+constexpr int kPrepSamples = 64;
+constexpr int kPrepWords = 16;
+
+__global__ __launch_bounds__(256) void prepare_planes_kernel(
+    const uint64_t *__restrict__ bits, uint32_t words_per_sample,
+    PlaneGeometry geo, uint4 *__restrict__ planes) {
+  __shared__ uint64_t het_lds[kPrepSamples][kPrepWords + 1];
+  __shared__ uint64_t hom_lds[kPrepSamples][kPrepWords + 1];
+
+  const uint32_t plane_words = words_per_sample / 2;
+  const uint32_t s0 = blockIdx.x * kPrepSamples;
+  const uint32_t w0 = blockIdx.y * kPrepWords;
+
+#pragma unroll
+  for (int it = 0; it < kPrepSamples * kPrepWords / 256; ++it) {
+    const uint32_t idx = it * 256 + threadIdx.x;
+    const uint32_t s = idx / kPrepWords, w = idx % kPrepWords;
+    const uint32_t ps = s0 + s;  // plane sample index
+    // Which stored sample of the reference bitset, if any.
+    uint32_t src = 0xFFFFFFFFu;
+    if (geo.diag || ps < geo.rows_padded) {
+      if (ps < geo.num_rows) src = ps;
+    } else {
+      const uint32_t c = ps - geo.col_base;
+      if (c < geo.num_cols) src = geo.num_rows + c;
+    }
+    uint64_t het = ~0ull, hom = ~0ull;  // missing
+    if (src != 0xFFFFFFFFu && w0 + w < plane_words) {
+      const uint64_t *p = bits + (uint64_t)src * words_per_sample + (w0 + w);
+      het = p[0];
+      hom = p[plane_words];
+    }
+    het_lds[s][w] = het;
+    hom_lds[s][w] = hom;
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int it = 0; it < kPrepSamples * kPrepWords * 2 / 256; ++it) {
+    const uint32_t idx = it * 256 + threadIdx.x;
+    const uint32_t krow = idx / kPrepSamples, s = idx % kPrepSamples;
+    const uint32_t k = w0 * 2 + krow;
+    if (k >= geo.k_words || s0 + s >= geo.s_stride) continue;
+    const uint32_t shift = (krow & 1) * 32;
+    const uint32_t het = (uint32_t)(het_lds[s][krow >> 1] >> shift);
+    const uint32_t hom = (uint32_t)(hom_lds[s][krow >> 1] >> shift);
+    uint4 v;
+    v.x = het & ~hom;    // H
+    v.y = hom & ~het;    // A
+    v.z = ~het;          // Hom (hom-ref or hom-alt)
+    v.w = ~(het & hom);  // D
+    planes[(uint64_t)k * geo.s_stride + s0 + s] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// king_tiled_kernel
+//
+// Workgroup = one TILE x TILE tile of sample pairs, TIT x TJT threads, each
+// owning an RI x RJ micro-tile (rows q*TIT + ti, columns q*TJT + tj) with five
+// u32 accumulators per pair.  K is streamed in chunks of KC 32-site words:
+// every chunk is 2 * KC rows of TILE uint4 (row side and column side), copied
+// global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave
+// instruction, no VGPR staging) into a double buffer while the previous chunk
+// is consumed with ds_read_b128.
+//
+// Per pair and 32-site word, 10 VALU ops:
+//     t    = Hom_i & Hom_j                       v_and
+//     hh  += popc(t)                             v_bcnt (accumulating)
+//     opp += popc((A_i ^ A_j) & t)               v_bitop3 + v_bcnt
+//     bh  += popc(H_i & H_j)                     v_and + v_bcnt
+//     hi  += popc(H_i & D_j)                     v_and + v_bcnt
+//     hj  += popc(D_i & H_j)                     v_and + v_bcnt
+// from which the reference's six sums (cuking.cu:232-239) follow exactly:
+//     het_i = hi, het_j = hj, both_het = bh, opposing_hom = opp,
+//     concordant_hom = hh - opp, shared = hi + hj - bh + hh.
+// ---------------------------------------------------------------------------
+template <int TIT, int TJT, int RI, int RJ, int KC, int KU, int MINW>
+__global__ __launch_bounds__(TIT *TJT, MINW) void king_tiled_kernel(
+    const TiledArgs a) {
+  constexpr int TILE = TIT * RI;
+  static_assert(TILE == TJT * RJ, "square tiles only");
+  constexpr int NT = TIT * TJT;
+  constexpr int NW = NT / 64;
+  constexpr int SEG = TILE / 64;            // 1 KiB wave-rows per tile row
+  constexpr int WAVE_ROWS = 2 * KC * SEG;   // per chunk
+  static_assert(WAVE_ROWS % NW == 0, "rows must split evenly over waves");
+  constexpr int PER_WAVE = WAVE_ROWS / NW;
+
+  extern __shared__ uint4 lds[];  // [2 buffers][2 sides][KC][TILE]
+
+  // --- which tile (uniform across the workgroup) ---
+  const uint64_t t = a.tile_begin + blockIdx.x;
+  uint32_t lo = 0, hi = a.tiles.num_bands();
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (a.band_prefix[mid] <= t) lo = mid; else hi = mid;
+  }
+  uint32_t tr, tc;
+  a.tiles.decode(lo, t - a.band_prefix[lo], &tr, &tc);
+
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t ti = threadIdx.x % TIT;
+  const uint32_t tj = threadIdx.x / TIT;
+
+  const uint4 *g_rows = a.planes + (uint64_t)tr * TILE;
+  const uint4 *g_cols = a.planes + a.geo.col_base + (uint64_t)tc * TILE;
+  const uint32_t s_stride = a.geo.s_stride;
+  const uint32_t num_chunks = a.geo.k_words / KC;
+
+  auto issue_chunk = [&](uint32_t chunk, uint32_t buf) {
+#pragma unroll
+    for (int r = 0; r < PER_WAVE; ++r) {
+      const uint32_t wr = wave * PER_WAVE + r;
+      const uint32_t side = wr / (KC * SEG);
+      const uint32_t rem = wr % (KC * SEG);
+      const uint32_t kc = rem / SEG, seg = rem % SEG;
+      const uint4 *src = (side ? g_cols : g_rows) +
+                         (uint64_t)(chunk * KC + kc) * s_stride + seg * 64 +
+                         lane;
+      uint4 *dst = lds + ((buf * 2 + side) * KC + kc) * TILE + seg * 64;
+      // LDS-DMA: lane l's 16 bytes land at dst + 16 * l.
+      __builtin_amdgcn_global_load_lds((global_void_ptr)src, (lds_void_ptr)dst,
+                                       16, 0, 0);
+    }
+  };
+
+  uint32_t c_hh[RI][RJ], c_opp[RI][RJ], c_bh[RI][RJ], c_hi[RI][RJ],
+      c_hj[RI][RJ];
+#pragma unroll
+  for (int x = 0; x < RI; ++x)
+#pragma unroll
+    for (int y = 0; y < RJ; ++y)
+      c_hh[x][y] = c_opp[x][y] = c_bh[x][y] = c_hi[x][y] = c_hj[x][y] = 0;
+
+  issue_chunk(0, 0);
+  for (uint32_t chunk = 0; chunk < num_chunks; ++chunk) {
+    const uint32_t buf = chunk & 1;
+    // Chunk `chunk` has landed (vmcnt) for every wave, and every wave is done
+    // reading the other buffer.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), leaves lgkmcnt/expcnt
+    __syncthreads();
+    if (chunk + 1 < num_chunks) issue_chunk(chunk + 1, buf ^ 1);
+
+    const uint4 *l_rows = lds + (buf * 2 + 0) * KC * TILE;
+    const uint4 *l_cols = lds + (buf * 2 + 1) * KC * TILE;
+    // Partial unroll only: a full unroll lets the scheduler hoist every
+    // k-step's ds_reads and spills hundreds of VGPRs.
+#pragma unroll(KU)
+    for (int kc = 0; kc < KC; ++kc) {
+      uint4 ri[RI], cj[RJ];
+#pragma unroll
+      for (int x = 0; x < RI; ++x) ri[x] = l_rows[kc * TILE + x * TIT + ti];
+#pragma unroll
+      for (int y = 0; y < RJ; ++y) cj[y] = l_cols[kc * TILE + y * TJT + tj];
+#pragma unroll
+      for (int x = 0; x < RI; ++x) {
+#pragma unroll
+        for (int y = 0; y < RJ; ++y) {
+          const uint32_t hom_both = ri[x].z & cj[y].z;
+          c_hh[x][y] += __builtin_popcount(hom_both);
+          c_opp[x][y] += __builtin_popcount(
+              __builtin_amdgcn_bitop3_b32(ri[x].y, cj[y].y, hom_both, 0x28));
+          c_bh[x][y] += __builtin_popcount(ri[x].x & cj[y].x);
+          c_hi[x][y] += __builtin_popcount(ri[x].x & cj[y].w);
+          c_hj[x][y] += __builtin_popcount(ri[x].w & cj[y].x);
+        }
+      }
+    }
+  }
+
+  // --- epilogue: kinship, threshold, append (cuking.cu:284-313) ---
+#pragma unroll
+  for (int x = 0; x < RI; ++x) {
+    const uint32_t li = tr * TILE + x * TIT + ti;  // row inside the block
+    if (li >= a.geo.num_rows) continue;
+    const uint32_t i = a.i_begin + li;
+#pragma unroll
+    for (int y = 0; y < RJ; ++y) {
+      const uint32_t lj = tc * TILE + y * TJT + tj;
+      if (lj >= a.geo.num_cols) continue;
+      const uint32_t j = a.j_begin + lj;
+      if (i >= j) continue;  // cuking.cu:199
+      const uint32_t het_i = c_hi[x][y], het_j = c_hj[x][y];
+      const uint32_t both_het = c_bh[x][y], opp = c_opp[x][y];
+      const uint32_t conc = c_hh[x][y] - opp;
+      const uint32_t shared = het_i + het_j - both_het + c_hh[x][y];
+      if (a.dense_counts != nullptr) {
+        cuking_counts c;
+        c.het_i = het_i;
+        c.het_j = het_j;
+        c.both_het = both_het;
+        c.opposing_hom = opp;
+        c.concordant_hom = conc;
+        c.shared = shared;
+        a.dense_counts[(uint64_t)li * a.geo.num_cols + lj] = c;
+        continue;
+      }
+      const float kin = king_kinship(het_i, het_j, both_het, opp);
+      if (kin > a.kin_threshold) {
+        const uint32_t ibs0 = opp, ibs2 = conc + both_het;
+        emit_result(i, j, kin, ibs0, shared - ibs0 - ibs2, ibs2, a.max_results,
+                    a.results, a.result_index, a.result_overflow);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// king_stream_kernel: one pair per wavefront, straight from the reference
+// layout; lanes stride over the 64-bit words (coalesced 512-byte rows), six
+// sums with the reference's own masks (cuking.cu:219-239), wave64 butterfly
+// reduction (replaces the 32-lane shuffle + shared-memory atomics of
+// cuking.cu:242-282: a pair never spans more than one wavefront here).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void king_stream_kernel(
+    const cuking_submatrix sm, const uint32_t words_per_sample,
+    const uint64_t *__restrict__ bits, const float kin_threshold,
+    const uint32_t max_results, cuking_result *results, uint32_t *result_index,
+    uint32_t *result_overflow, cuking_counts *dense_counts) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t num_cols = sm_num_cols(sm);
+  const uint32_t col_groups = (num_cols + 3) / 4;
+  const uint64_t b = blockIdx.x;
+  const uint32_t li = (uint32_t)(b / col_groups);
+  const uint32_t lj = (uint32_t)(b % col_groups) * 4 + wave;
+  const uint32_t i = sm.i_begin + li, j = sm.j_begin + lj;
+  if (lj >= num_cols || i >= j) return;  // whole wavefront leaves together
+
+  const uint32_t n = words_per_sample / 2;
+  const uint64_t *het_i_w =
+      bits + (uint64_t)sm_sample_offset(sm, i) * words_per_sample;
+  const uint64_t *alt_i_w = het_i_w + n;
+  const uint64_t *het_j_w =
+      bits + (uint64_t)sm_sample_offset(sm, j) * words_per_sample;
+  const uint64_t *alt_j_w = het_j_w + n;
+
+  uint32_t s_het_i = 0, s_het_j = 0, s_both = 0, s_opp = 0, s_conc = 0,
+           s_shared = 0;
+  for (uint32_t k = lane; k < n; k += 64) {
+    const uint64_t hi = het_i_w[k], ai = alt_i_w[k];
+    const uint64_t hj = het_j_w[k], aj = alt_j_w[k];
+    const uint64_t ri = ~(hi | ai), rj = ~(hj | aj);
+    const uint64_t defined = ~((hi & ai) | (hj & aj));
+    s_het_i += __popcll(hi & defined);
+    s_het_j += __popcll(hj & defined);
+    s_both += __popcll(hi & hj & defined);
+    s_opp += __popcll(((ri & aj) | (ai & rj)) & defined);
+    s_conc += __popcll(((ri & rj) | (ai & aj)) & defined);
+    s_shared += __popcll(defined);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s_het_i += __shfl_xor(s_het_i, off);
+    s_het_j += __shfl_xor(s_het_j, off);
+    s_both += __shfl_xor(s_both, off);
+    s_opp += __shfl_xor(s_opp, off);
+    s_conc += __shfl_xor(s_conc, off);
+    s_shared += __shfl_xor(s_shared, off);
+  }
+  if (lane != 0) return;
+  if (dense_counts != nullptr) {
+    cuking_counts c;
+    c.het_i = s_het_i;
+    c.het_j = s_het_j;
+    c.both_het = s_both;
+    c.opposing_hom = s_opp;
+    c.concordant_hom = s_conc;
+    c.shared = s_shared;
+    dense_counts[(uint64_t)li * num_cols + lj] = c;
+    return;
+  }
+  const float kin = king_kinship(s_het_i, s_het_j, s_both, s_opp);
+  if (kin > kin_threshold) {
+    const uint32_t ibs0 = s_opp, ibs2 = s_conc + s_both;
+    emit_result(i, j, kin, ibs0, s_shared - ibs0 - ibs2, ibs2, max_results,
+                results, result_index, result_overflow);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// pack_kernel: cuking.cu:675-703 with device atomics (AtomicClearBit :317-323).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_kernel(
+    const cuking_submatrix sm, const uint32_t words_per_sample,
+    uint64_t *bit_set, const int64_t *__restrict__ row_idx,
+    const int64_t *__restrict__ col_idx, const int32_t *__restrict__ n_alt,
+    const uint64_t num_triples, uint32_t *status) {
+  const uint32_t plane_words = words_per_sample / 2;
+  const uint64_t plane_bits = (uint64_t)plane_words * 64;
+  uint32_t bad = 0;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       t < num_triples; t += (uint64_t)gridDim.x * blockDim.x) {
+    const int64_t col = col_idx[t];
+    if (col < 0 || col > 0xFFFFFFFFll || !sm_contains(sm, (uint32_t)col))
+      continue;  // :677-679
+    const int64_t row = row_idx[t];
+    if (row < 0 || (uint64_t)row >= plane_bits) {
+      bad |= 2u;
+      continue;
+    }
+    unsigned long long *het = reinterpret_cast<unsigned long long *>(
+        bit_set + (uint64_t)sm_sample_offset(sm, (uint32_t)col) *
+                      words_per_sample);
+    unsigned long long *hom = het + plane_words;
+    const unsigned long long clear = ~(1ull << (row & 63));
+    const uint64_t word = (uint64_t)row >> 6;
+    const int32_t g = n_alt[t];
+    if (g == 0) {  // hom-ref
+      atomicAnd(het + word, clear);
+      atomicAnd(hom + word, clear);
+    } else if (g == 1) {  // het keeps its het bit
+      atomicAnd(hom + word, clear);
+    } else if (g == 2) {  // hom-var keeps its hom_var bit
+      atomicAnd(het + word, clear);
+    } else {
+      bad |= 1u;  // :698-702
+    }
+  }
+  if (bad) atomicOr(status, bad);
+}
+
+template <int TIT, int TJT, int RI, int RJ, int KC, int KU, int MINW>
+hipError_t launch_variant(const TiledArgs &args, uint64_t num_tiles,
+                          uint32_t lds_bytes, hipStream_t stream) {
+  auto kernel = king_tiled_kernel<TIT, TJT, RI, RJ, KC, KU, MINW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void *>(kernel),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  // Grid x is limited to 2^31 - 1 workgroups; split larger tile ranges.
+  uint64_t done = 0;
+  while (done < num_tiles) {
+    const uint64_t n = (num_tiles - done < (1ull << 30)) ? num_tiles - done
+                                                        : (1ull << 30);
+    TiledArgs a = args;
+    a.tile_begin = args.tile_begin + done;
+    kernel<<<dim3((uint32_t)n), dim3(TIT * TJT), lds_bytes, stream>>>(a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    done += n;
+  }
+  return hipSuccess;
+}
+
+const TiledVariant kVariants[kNumTiledVariants] = {
+    {"t64_r4x4_k8_w4", 64, 8, 256, 2 * 2 * 8 * 64 * 16},
+    {"t128_r8x4_k8_w2", 128, 8, 512, 2 * 2 * 8 * 128 * 16},
+    {"t128_r4x4_k8_w4", 128, 8, 1024, 2 * 2 * 8 * 128 * 16},
+    {"t64_r4x4_k16_w4", 64, 16, 256, 2 * 2 * 16 * 64 * 16},
+};
+
+}  // namespace
+
+const TiledVariant &tiled_variant(int v) { return kVariants[v]; }
+
+hipError_t launch_tiled(int variant, const TiledArgs &args, uint64_t num_tiles,
+                        hipStream_t stream) {
+  if (num_tiles == 0) return hipSuccess;
+  const uint32_t lds = kVariants[variant].lds_bytes;
+  switch (variant) {
+    case 0: return launch_variant<16, 16, 4, 4, 8, 2, 4>(args, num_tiles, lds, stream);
+    case 1: return launch_variant<16, 32, 8, 4, 8, 2, 2>(args, num_tiles, lds, stream);
+    case 2: return launch_variant<32, 32, 4, 4, 8, 2, 4>(args, num_tiles, lds, stream);
+    case 3: return launch_variant<16, 16, 4, 4, 16, 2, 4>(args, num_tiles, lds, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_prepare_planes(const uint64_t *d_bit_sets,
+                                 uint32_t words_per_sample,
+                                 const PlaneGeometry &geo, uint4 *d_planes,
+                                 hipStream_t stream) {
+  const dim3 grid((geo.s_stride + kPrepSamples - 1) / kPrepSamples,
+                  (geo.k_words + 2 * kPrepWords - 1) / (2 * kPrepWords));
+  if (grid.x == 0 || grid.y == 0) return hipSuccess;
+  prepare_planes_kernel<<<grid, dim3(256), 0, stream>>>(
+      d_bit_sets, words_per_sample, geo, d_planes);
+  return hipGetLastError();
+}
+
+hipError_t launch_stream(const cuking_submatrix &sm, uint32_t words_per_sample,
+                         const uint64_t *d_bit_sets, float kin_threshold,
+                         uint32_t max_results, cuking_result *d_results,
+                         uint32_t *d_result_index, uint32_t *d_result_overflow,
+                         cuking_counts *d_dense_counts, hipStream_t stream) {
+  const uint64_t rows = sm_num_rows(sm);
+  const uint64_t col_groups = ((uint64_t)sm_num_cols(sm) + 3) / 4;
+  const uint64_t blocks = rows * col_groups;
+  if (blocks == 0) return hipSuccess;
+  if (blocks >= (1ull << 31)) return hipErrorInvalidValue;
+  king_stream_kernel<<<dim3((uint32_t)blocks), dim3(256), 0, stream>>>(
+      sm, words_per_sample, d_bit_sets, kin_threshold, max_results, d_results,
+      d_result_index, d_result_overflow, d_dense_counts);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack(const cuking_submatrix &sm, uint32_t words_per_sample,
+                       uint64_t *d_bit_set, const int64_t *d_row_idx,
+                       const int64_t *d_col_idx, const int32_t *d_n_alt,
+                       size_t num_triples, uint32_t *d_status,
+                       hipStream_t stream) {
+  if (num_triples == 0) return hipSuccess;
+  uint64_t blocks = (num_triples + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride the rest
+  pack_kernel<<<dim3((uint32_t)blocks), dim3(256), 0, stream>>>(
+      sm, words_per_sample, d_bit_set, d_row_idx, d_col_idx, d_n_alt,
+      num_triples, d_status);
+  return hipGetLastError();
+}
+
+}  // namespace cuking

@@ -1,0 +1,241 @@
+/*
+ * cuking_amd.h -- C ABI of the MI355X-native KING hot path.
+ *
+ * The reference (populationgenomics/cuKING, cuking.cu) has no library or FFI
+ * boundary: its one kernel is launched inline from Run() (cuking.cu:734-741).
+ * This header is the boundary a maintainer would bind instead.  Each entry
+ * point cites the reference lines it replaces.  Conventions:
+ *
+ *   - extern "C", plain pointers and sizes, POD structs only; no C++ or torch
+ *     types cross the boundary.
+ *   - every function returns a cuking_status (0 = OK) unless it is a pure
+ *     size/index helper; cuking_last_error() gives the message.
+ *   - pointers named d_* are DEVICE pointers (hipMalloc'd, or e.g. a torch
+ *     tensor's data_ptr()); everything else is host memory owned by the caller.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *     Calls enqueue work on it and return without synchronising unless stated.
+ *   - one context per GPU; a context is used by one host thread at a time.
+ *   - there is no CPU fallback: without a usable gfx950 device every device
+ *     entry point fails with CUKING_ERR_DEVICE.
+ */
+#ifndef CUKING_AMD_H_
+#define CUKING_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CUKING_ABI_VERSION 1
+
+typedef enum cuking_status {
+  CUKING_OK = 0,
+  CUKING_ERR_INVALID_ARGUMENT = 1,    /* absl::InvalidArgument, cuking.cu:437-462 */
+  CUKING_ERR_FAILED_PRECONDITION = 2, /* e.g. bad n_alt_alleles, cuking.cu:698-702 */
+  CUKING_ERR_RESOURCE_EXHAUSTED = 3,  /* result overflow, cuking.cu:747-751 */
+  CUKING_ERR_OUT_OF_MEMORY = 4,       /* cuking.cu:113-118 */
+  CUKING_ERR_DEVICE = 5               /* any HIP failure (unchecked in the reference, :738-744) */
+} cuking_status;
+
+/* cuking.cu:129-179 (struct Submatrix): one block of the upper-triangular
+ * block matrix of sample pairs.  Samples are stored rows first, then columns;
+ * a diagonal block stores its samples once. */
+typedef struct cuking_submatrix {
+  uint32_t i_begin, i_end; /* sample row range    */
+  uint32_t j_begin, j_end; /* sample column range */
+} cuking_submatrix;
+
+/* cuking.cu:182-186 (struct KingResult), 24 bytes. */
+typedef struct cuking_result {
+  uint32_t sample_i, sample_j;
+  float kin;
+  uint32_t ibs0, ibs1, ibs2;
+} cuking_result;
+
+/* The six per-pair sums of cuking.cu:216-240 (diagnostic output only). */
+typedef struct cuking_counts {
+  uint32_t het_i, het_j, both_het, opposing_hom, concordant_hom, shared;
+} cuking_counts;
+
+/* ------------------------------------------------------------------------ */
+/* Host-only helpers (no GPU touched).                                       */
+/* ------------------------------------------------------------------------ */
+
+/* cuking.cu:130-152 + flag validation :455-462.  Ranges are clamped to
+ * num_samples (the reference wraps when block*size > N). */
+cuking_status cuking_submatrix_init(cuking_submatrix *sm, uint32_t num_samples,
+                                    uint32_t split_factor,
+                                    uint32_t shard_index);
+uint32_t cuking_submatrix_num_rows(const cuking_submatrix *sm);    /* :154 */
+uint32_t cuking_submatrix_num_cols(const cuking_submatrix *sm);    /* :156 */
+uint32_t cuking_submatrix_num_samples(const cuking_submatrix *sm); /* :159-162 */
+uint32_t cuking_submatrix_contains(const cuking_submatrix *sm, uint32_t index);      /* :165-168 */
+uint32_t cuking_submatrix_sample_offset(const cuking_submatrix *sm, uint32_t index); /* :171-175 */
+/* Number of (i < j) pairs the block holds = what the kernel evaluates (:199). */
+uint64_t cuking_submatrix_num_pairs(const cuking_submatrix *sm);
+
+uint32_t cuking_padded_sites(uint32_t num_sites);     /* :498-500 (x32) */
+uint32_t cuking_words_per_sample(uint32_t num_sites); /* :513 */
+/* Algorithmic bytes one pair reads: 2 samples x words_per_sample x 8 (:209-224). */
+uint64_t cuking_bytes_per_pair(uint32_t words_per_sample);
+
+/* cuking.cu:675-703 + :317-323 on HOST memory: clears bits of an all-ones
+ * (cuking.cu:523) bitset for each triple whose sample is in the block.
+ * Relaxed atomic ANDs, so concurrent calls on one bitset from several reader
+ * threads are safe (cuking.cu:550-553).  FAILED_PRECONDITION for n_alt outside
+ * {0,1,2}; INVALID_ARGUMENT for a row_idx outside the padded sites. */
+cuking_status cuking_pack_host(const cuking_submatrix *sm,
+                               uint32_t words_per_sample, uint64_t *bit_set,
+                               const int64_t *row_idx, const int64_t *col_idx,
+                               const int32_t *n_alt_alleles,
+                               size_t num_triples);
+
+/* Message of the calling thread's most recent failing call ("" if none). */
+const char *cuking_last_error(void);
+uint32_t cuking_abi_version(void);
+
+/* ------------------------------------------------------------------------ */
+/* Device context and memory.                                                */
+/* ------------------------------------------------------------------------ */
+typedef struct cuking_ctx cuking_ctx;
+
+int cuking_device_count(void);
+/* Binds a context to HIP device `device` (must be gfx950). */
+cuking_status cuking_ctx_create(int device, cuking_ctx **out);
+void cuking_ctx_destroy(cuking_ctx *ctx);
+
+/* Explicit device memory for hosts without their own allocator (replaces
+ * cudaMallocManaged, cuking.cu:109-120: no managed memory on the hot path). */
+cuking_status cuking_device_alloc(cuking_ctx *ctx, size_t bytes, void **d_ptr);
+cuking_status cuking_device_free(cuking_ctx *ctx, void *d_ptr);
+cuking_status cuking_memset_async(cuking_ctx *ctx, void *d_ptr, int byte_value,
+                                  size_t bytes, void *stream);
+cuking_status cuking_copy_to_device(cuking_ctx *ctx, void *d_dst,
+                                    const void *src, size_t bytes, void *stream);
+cuking_status cuking_copy_to_host(cuking_ctx *ctx, void *dst, const void *d_src,
+                                  size_t bytes, void *stream);
+cuking_status cuking_stream_synchronize(cuking_ctx *ctx, void *stream);
+/* Page-locked host memory for staging buffers. */
+cuking_status cuking_host_alloc(cuking_ctx *ctx, size_t bytes, void **ptr);
+cuking_status cuking_host_free(cuking_ctx *ctx, void *ptr);
+
+/* ------------------------------------------------------------------------ */
+/* The hot path.                                                             */
+/* ------------------------------------------------------------------------ */
+
+/* Pack on the device (cuking.cu:675-703 as a kernel): d_bit_set must already
+ * be all ones (cuking.cu:523; cuking_memset_async(.., 0xFF, ..)).  Triples
+ * live in device memory.  *d_status (one u32, zeroed by the caller) receives
+ * a bit mask: 1 = n_alt outside {0,1,2}, 2 = row_idx out of range. */
+cuking_status cuking_pack_device(cuking_ctx *ctx, const cuking_submatrix *sm,
+                                 uint32_t words_per_sample, uint64_t *d_bit_set,
+                                 const int64_t *d_row_idx,
+                                 const int64_t *d_col_idx,
+                                 const int32_t *d_n_alt_alleles,
+                                 size_t num_triples, uint32_t *d_status,
+                                 void *stream);
+
+/* Which device kernel evaluates the pairs. */
+typedef enum cuking_kernel {
+  CUKING_KERNEL_TILED = 0,  /* LDS-staged, register-tiled popcount kernel (default) */
+  CUKING_KERNEL_STREAM = 1  /* one pair per wavefront, wave-level reductions */
+} cuking_kernel;
+cuking_status cuking_ctx_set_kernel(cuking_ctx *ctx, cuking_kernel kernel);
+/* Tuning knobs of the tiled kernel: "variant" (compiled tile shape, 0 ..
+ * cuking_num_variants()-1; also env CUKING_AMD_VARIANT) and "band_rows"
+ * (tile-rows per scheduling band, 1..64; env CUKING_AMD_BAND_ROWS).  Results
+ * do not depend on either. */
+cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
+                                    int64_t value);
+int cuking_num_variants(void);
+const char *cuking_variant_name(int variant);
+
+/* ComputeKingKernel (cuking.cu:191-314) with its launch (:725-741): same
+ * arguments, same meaning.  For every pair (i < j) of the block computes the
+ * six masked popcount sums over d_bit_sets (layout cuking.cu:507-523: sample
+ * s at d_bit_sets + SampleOffset(s) * words_per_sample, [het | hom_var]
+ * planes), the float32 kinship (:289-294), and appends a cuking_result for
+ * each pair with kin > kin_threshold (strict) at slot atomicAdd(d_result_index)
+ * if that slot < max_results, else sets *d_result_overflow = 1 (:297-313).
+ * d_result_index and d_result_overflow are NOT reset by the call (the caller
+ * zeroes them, like cuking.cu:721-722), so several calls may append to one
+ * buffer.  Record order is unspecified (sort afterwards, :761-765).
+ * Asynchronous on `stream`. */
+cuking_status cuking_compute_king(cuking_ctx *ctx, const cuking_submatrix *sm,
+                                  uint32_t words_per_sample,
+                                  const uint64_t *d_bit_sets,
+                                  float kin_threshold, uint32_t max_results,
+                                  cuking_result *d_results,
+                                  uint32_t *d_result_index,
+                                  uint32_t *d_result_overflow, void *stream);
+
+/* Pair-space sharding inside one block (replaces multi-VM --split_factor
+ * fan-out, cloud_batch_submit.py:45,73, for the GPUs of one node): the tiled
+ * kernel enumerates the block's pairs as cuking_num_tiles() independent
+ * square tiles; a rank evaluates tiles [tile_begin, tile_end).  The union of
+ * disjoint ranges covering [0, num_tiles) equals cuking_compute_king(). */
+uint64_t cuking_num_tiles(const cuking_ctx *ctx, const cuking_submatrix *sm);
+uint32_t cuking_tile_samples(const cuking_ctx *ctx); /* samples per tile edge */
+/* Which tile of the block tile index `tile` is: rows [*row_begin, *row_end)
+ * x columns [*col_begin, *col_end) in global sample indices (clamped to the
+ * block).  Host-only; lets a scheduler reason about the samples a tile range
+ * touches. */
+cuking_status cuking_tile_bounds(const cuking_ctx *ctx,
+                                 const cuking_submatrix *sm, uint64_t tile,
+                                 uint32_t *row_begin, uint32_t *row_end,
+                                 uint32_t *col_begin, uint32_t *col_end);
+/* (ctx may be NULL for these three: the default kernel shape is assumed.) */
+cuking_status cuking_compute_king_tiles(
+    cuking_ctx *ctx, const cuking_submatrix *sm, uint32_t words_per_sample,
+    const uint64_t *d_bit_sets, uint64_t tile_begin, uint64_t tile_end,
+    float kin_threshold, uint32_t max_results, cuking_result *d_results,
+    uint32_t *d_result_index, uint32_t *d_result_overflow, void *stream);
+
+/* Diagnostic: the six sums of every pair, no threshold.  d_counts holds
+ * NumRows x NumCols records, pair (i, j) at [(i - i_begin) * NumCols +
+ * (j - j_begin)]; entries with i >= j are left untouched. */
+cuking_status cuking_compute_counts(cuking_ctx *ctx, const cuking_submatrix *sm,
+                                    uint32_t words_per_sample,
+                                    const uint64_t *d_bit_sets,
+                                    cuking_counts *d_counts, void *stream);
+
+/* cuking.cu:761-765 on host memory: sort by (sample_i, sample_j, kin). */
+void cuking_sort_results(cuking_result *results, size_t num_results);
+
+/* ------------------------------------------------------------------------ */
+/* Measurement hooks (replace the StopWatch prints, cuking.cu:325-337).      */
+/* ------------------------------------------------------------------------ */
+
+/* When enabled, every launch of the pair kernel is bracketed by HIP events on
+ * the stream it is launched on. */
+cuking_status cuking_timing_enable(cuking_ctx *ctx, int enabled);
+cuking_status cuking_timing_reset(cuking_ctx *ctx);
+/* Synchronises the recorded events; returns total device milliseconds and
+ * the number of launches since the last reset, for the pair kernel and for
+ * the layout-preparation kernel that precedes it. */
+cuking_status cuking_timing_collect(cuking_ctx *ctx, double *king_ms,
+                                    uint64_t *king_launches, double *prepare_ms,
+                                    uint64_t *prepare_launches);
+
+/* ------------------------------------------------------------------------ */
+/* Synthetic inputs for benchmarks (no reference counterpart).    */
+/* ------------------------------------------------------------------------ */
+
+/* Fills rows [sample_begin, sample_end) of a reference-layout bitset with
+ * Hardy-Weinberg genotypes (per-site AF ~ U(0.05,0.5), 1 % missing) and the
+ * planted relatives described by kind/pa/pb (device arrays of num_samples
+ * u32 each; 0 founder, 1 duplicate of pa, 2 child of pa x pb).  Row 0 of
+ * d_bit_set is sample_begin.  Bit-identical to oracle/synth_oracle.c. */
+cuking_status cuking_synth_bitset(cuking_ctx *ctx, uint64_t seed,
+                                  const uint32_t *d_kind, const uint32_t *d_pa,
+                                  const uint32_t *d_pb, uint32_t sample_begin,
+                                  uint32_t sample_end, uint32_t num_sites,
+                                  uint32_t words_per_sample,
+                                  uint64_t *d_bit_set, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUKING_AMD_H_ */
