@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""All-pairs KING throughput on MI355X (BASELINE.json metric: sample-pairs/s +
+achieved HBM GB/s vs roofline).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one pass of the hot path over one synthetic cohort whose packed
+bitset is already resident in HBM (reference layout, cuking.cu:507-523):
+layout preparation + the tiled pair kernel over every (i < j) pair +
+thresholded append of KingResult records.  For N > 1 a step is the sharded
+pass of cuking_amd/dist.py: RCCL broadcast of the bitset from rank 0, every
+rank evaluates its range of pair-space tiles, records gathered on rank 0.
+
+N = 1 workload: BASELINE.json configs[1], 10k samples x 100k sites,
+kin-threshold 0.05.  N > 1 (weak scaling): the same sites and threshold with
+round(10000 * sqrt(N)) samples, i.e. the same number of pairs per GPU.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CU x 4 SIMD-32 x 2.4 GHz
+VALU_OPS_PER_PAIR_WORD = 10     # king_kernels.hip: ops per pair per 32 sites
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--samples", type=int, default=0, help="override N samples")
+    ap.add_argument("--sites", type=int, default=100000)
+    ap.add_argument("--kin-threshold", type=float, default=0.05)
+    ap.add_argument("--max-results", type=int, default=1 << 20)
+    ap.add_argument("--kernel", default="tiled", choices=["tiled", "stream"])
+    ap.add_argument("--variant", type=int, default=-1)
+    ap.add_argument("--band-rows", type=int, default=-1)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0,
+                    help="target CPU-baseline time (0 disables it)")
+    ap.add_argument("--seed", type=int, default=20240229)
+    return ap.parse_args()
+
+
+def cpu_baseline(host_bits_fn, wps, gpu_records, thr, target_seconds):
+    """Times the oracle (oracle/king_oracle.c, -march=native, OpenMP over rows)
+    on a leading sub-block of the SAME cohort, and checks the GPU's records for
+    that sub-block against it.  Test-infrastructure use only."""
+    import tempfile
+    import numpy as np
+    from oracle import pyoracle
+    threads = len(os.sched_getaffinity(0))
+    out_dir = Path(tempfile.mkdtemp(prefix="cuking_oracle_"))
+    lib = pyoracle.load(native=True, out_dir=out_dir)
+    os.environ.setdefault("OMP_PROC_BIND", "true")
+
+    def run(s):
+        import ctypes as C
+        bits = host_bits_fn(s)
+        sm = pyoracle.submatrix(s)
+        res = np.zeros(1 << 20, dtype=pyoracle.RESULT_DTYPE)
+        ovf = C.c_uint32(0)
+        t0 = time.perf_counter()
+        n = lib.orc_compute_mt(C.byref(sm), wps, bits.ctypes.data_as(C.c_void_p),
+                               thr, res.size, res.ctypes.data_as(C.c_void_p),
+                               C.byref(ovf), threads)
+        dt = time.perf_counter() - t0
+        res = res[:n].copy()
+        lib.orc_sort(res.ctypes.data_as(C.c_void_p), res.size)
+        return s * (s - 1) // 2, dt, res
+
+    pairs, dt, _ = run(256)                      # calibration
+    rate = pairs / dt
+    s = int(min(4096, max(256, math.sqrt(2 * rate * target_seconds))))
+    pairs, dt, res = run(s)
+    sel = gpu_records[(gpu_records["sample_j"] < s)]
+    if sel.tobytes() != res.tobytes():
+        raise SystemExit(f"PARITY FAILURE: GPU records for the first {s} samples "
+                         "differ from the CPU oracle")
+    return {"value": pairs / dt, "unit": "sample-pairs/s", "cores": threads,
+            "kind": "port",
+            "sample": f"first {s} samples ({pairs} pairs) of the same cohort, "
+                      f"{dt:.1f} s, OpenMP x{threads}, -O3 -march=native; "
+                      "records checked equal to the GPU's"}
+
+
+def load_traffic(workload_key):
+    """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/),
+    corrected as MI355X_MICROARCH.md prescribes; None if not measured for this
+    workload."""
+    p = ROOT / "profiles" / "hbm_traffic.json"
+    if not p.exists():
+        return None
+    try:
+        return json.loads(p.read_text()).get(workload_key, {}).get("traffic_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import cuking_amd
+    from cuking_amd.dist import all_pairs_king, tile_partition
+    from cuking_amd.synth import cohort_to_device, plan_cohort
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with "
+                         "torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    n = args.samples or int(round(10000 * math.sqrt(world)))
+    m = args.sites
+    thr = args.kin_threshold
+    wps = cuking_amd.words_per_sample(m)
+    sm = cuking_amd.Submatrix(n)
+    pairs = sm.NumPairs()
+
+    ctx = cuking_amd.KingContext(local_rank)
+    ctx.set_kernel(args.kernel)
+    if args.variant >= 0:
+        ctx.set_option("variant", args.variant)
+    if args.band_rows > 0:
+        ctx.set_option("band_rows", args.band_rows)
+    ctx.timing_enable(True)
+
+    # Synthetic cohort, generated on the device (rank 0 owns the "packed
+    # input"; the other ranks receive it by broadcast inside every step).
+    cohort = plan_cohort(n, args.seed)
+    kind, pa, pb = cohort_to_device(cohort, local_rank)
+    bits = torch.zeros((n, wps), dtype=torch.int64, device=dev)
+    if rank == 0:
+        ctx.synth_bitset(args.seed, kind, pa, pb, 0, n, m, out=bits)
+    torch.cuda.synchronize()
+
+    results = torch.zeros((args.max_results, 6), dtype=torch.int32, device=dev)
+    index_flag = torch.zeros(2, dtype=torch.int32, device=dev)
+    num_tiles = ctx.num_tiles(sm) if args.kernel == "tiled" else 0
+    my_tiles = tile_partition(num_tiles, world)[rank] if world > 1 else None
+
+    def compute_tiles(bit_sets, begin, end):
+        index_flag.zero_()
+        ctx.compute_king(sm, wps, bit_sets, thr, args.max_results, results,
+                         index_flag[0:1], index_flag[1:2], tile_range=(begin, end))
+        count, ovf = index_flag.tolist()   # waits for the kernel
+        return results, count, ovf
+
+    gathered = [None]
+
+    def step():
+        if world == 1:
+            index_flag.zero_()
+            ctx.compute_king(sm, wps, bits, thr, args.max_results, results,
+                             index_flag[0:1], index_flag[1:2])
+        else:
+            gathered[0], _ = all_pairs_king(compute_tiles, num_tiles, bits)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    timing = ctx.timing_collect()
+    # Records of the last step (rank 0): sanity + parity material.
+    if world == 1:
+        count, ovf = index_flag.tolist()
+        if ovf:
+            raise SystemExit("result overflow: raise --max-results")
+        recs = results[:count].cpu().numpy().view(np.uint32).reshape(-1).view(
+            cuking_amd.KING_RESULT_DTYPE).copy()
+        recs = cuking_amd.sort_results(recs)
+    else:
+        recs = gathered[0]
+
+    out = None
+    if rank == 0:
+        got = {(int(r["sample_i"]), int(r["sample_j"])) for r in recs}
+        missing = [p for p in cohort.planted
+                   if (min(p[0], p[1]), max(p[0], p[1])) not in got]
+        if missing:
+            raise SystemExit(f"{len(missing)} planted relatives not reported")
+
+        ms_per_step = elapsed / args.steps * 1e3
+        value = pairs * args.steps / elapsed
+        bpp = cuking_amd.bytes_per_pair(wps)
+        # Dominant kernel = the pair kernel; rank 0's launches cover its own
+        # share of the pairs.
+        launch_pairs = pairs if world == 1 else pairs * (my_tiles[1] - my_tiles[0]) / max(num_tiles, 1)
+        king_ms = timing.king_ms / max(timing.king_launches, 1)
+        achieved = launch_pairs * bpp / (king_ms * 1e-3) / 1e9 if king_ms > 0 else 0.0
+        workload = f"{n} samples x {m} sites, kin-threshold {thr}"
+        key = f"{n}x{m}"
+        roofline = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": load_traffic(key) if world == 1 else None,
+            "kernel": f"king_{args.kernel}_kernel",
+            "kernel_ms": king_ms, "launches": timing.king_launches,
+            "algorithmic_bytes_per_pair": bpp,
+            "note": "algorithmic bytes (2 samples x words_per_sample x 8 B per pair) / "
+                    "measured kernel time; the tiled kernel re-uses operands from LDS and "
+                    "registers, so this exceeds 1.0 of HBM peak by design (it is VALU-bound)",
+            "valu": {
+                "achieved_lane_ops_per_s": launch_pairs * wps * VALU_OPS_PER_PAIR_WORD / (king_ms * 1e-3) if king_ms > 0 else 0.0,
+                "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
+            },
+            "prepare_ms": timing.prepare_ms / max(timing.prepare_launches, 1),
+        }
+        roofline["valu"]["frac"] = roofline["valu"]["achieved_lane_ops_per_s"] / VALU_PEAK_LANE_OPS
+        out = {
+            "metric": "sample-pairs/s (all-pairs KING)", "value": value,
+            "unit": "sample-pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": workload, "samples": n, "sites": m,
+                       "pairs": pairs, "kin_threshold": thr,
+                       "results_per_step": int(len(recs)),
+                       "kernel": args.kernel,
+                       "parallelism": f"pair-space tiles over {world} GPU(s)"},
+            "roofline": roofline,
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            def host_bits(s):
+                return np.ascontiguousarray(bits[:s].cpu().numpy().view(np.uint64))
+            out["cpu_baseline"] = cpu_baseline(host_bits, wps, recs, thr, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -54,11 +54,12 @@ def build_library(force: bool = False, save_temps: bool = False) -> Path:
         return LIB_PATH
     cmd = [_hipcc(), *HIP_FLAGS, "-shared", f"-I{INCLUDE}", f"-I{CSRC}",
            *map(str, srcs), "-o", str(LIB_PATH)]
-    if save_temps:
-        tmp = PKG / "build_tmp"
-        tmp.mkdir(exist_ok=True)
-        cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
-    subprocess.run(cmd, check=True, cwd=str(PKG))
+    cwd = PKG
+    if save_temps:  # keeps the .s / resource-usage remarks for inspection
+        cwd = PKG / "build_tmp"
+        cwd.mkdir(exist_ok=True)
+        cmd += ["-save-temps", "-Rpass-analysis=kernel-resource-usage"]
+    subprocess.run(cmd, check=True, cwd=str(cwd))
     return LIB_PATH
 
 

@@ -1,0 +1,204 @@
+"""CPU tests of the product's host side: the C ABI library loads, exports every
+symbol include/cuking_amd.h declares, and its host-only helpers agree with the
+oracle.  No compute calls (there is no GPU here) -- and no CPU fallback: the
+device entry points must fail loudly without a gfx950 device."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import cuking_amd
+from cuking_amd import _lib
+from conftest import ROOT, random_genotypes
+
+
+def has_gpu():
+    return cuking_amd.device_count() > 0
+
+
+def declared_symbols():
+    text = (ROOT / "include" / "cuking_amd.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cuking_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 40
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in the header, not exported"
+    # and the binding table covers exactly the header
+    assert sorted(_lib.SIGNATURES) == names
+    assert lib.cuking_abi_version() == 1
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary must be consumable from C (no C++ / torch types)."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "cuking_amd.h"\n'
+                   "int main(void) { cuking_result r; cuking_submatrix s;"
+                   " (void)r; (void)s; return sizeof(cuking_result) == 24 ? 0 : 1; }\n")
+    exe = tmp_path / "t"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic",
+                    f"-I{ROOT / 'include'}", str(src), "-o", str(exe)],
+                   check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 10, 37, 100, 734000])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 7])
+def test_submatrix_matches_oracle(oracle, n, k):
+    olib = oracle.load()
+    for shard in range(k * (k + 1) // 2):
+        sm = cuking_amd.Submatrix(n, k, shard)
+        osm = oracle.submatrix(n, k, shard)
+        assert sm.as_tuple() == osm.as_tuple()
+        assert sm.NumRows() == olib.orc_num_rows(C.byref(osm))
+        assert sm.NumCols() == olib.orc_num_cols(C.byref(osm))
+        assert sm.NumSamples() == olib.orc_num_samples(C.byref(osm))
+        probe = {0, n - 1, n // 2, sm.i_begin, max(sm.i_end, 1) - 1, sm.j_begin,
+                 max(sm.j_end, 1) - 1}
+        for s in probe:
+            if 0 <= s < n:
+                assert sm.Contains(s) == bool(olib.orc_contains(C.byref(osm), s))
+                if sm.Contains(s):
+                    assert sm.SampleOffset(s) == olib.orc_sample_offset(C.byref(osm), s)
+        # pairs the block holds
+        if n <= 100:
+            exp = sum(1 for i in range(sm.i_begin, sm.i_end)
+                      for j in range(max(sm.j_begin, i + 1), sm.j_end))
+            assert sm.NumPairs() == exp
+    with pytest.raises(cuking_amd.CukingError) as e:
+        cuking_amd.Submatrix(n, k, k * (k + 1) // 2)
+    assert e.value.status == _lib.ERR_INVALID_ARGUMENT
+    assert "Invalid shard index" in e.value.message       # cuking.cu:461
+    with pytest.raises(cuking_amd.CukingError) as e:
+        cuking_amd.Submatrix(n, 0, 0)
+    assert "Invalid split factor" in e.value.message      # cuking.cu:456
+
+
+def test_sizing_matches_oracle_and_survey(oracle):
+    olib = oracle.load()
+    for m in list(range(1, 200)) + [10000, 100000, 150000, 200000, 4194304]:
+        assert cuking_amd.padded_sites(m) == olib.orc_padded_sites(m)
+        assert cuking_amd.words_per_sample(m) == olib.orc_words_per_sample(m)
+    # algorithmic bytes per pair
+    for m, b in ((10000, 5024), (100000, 50016), (150000, 75008), (200000, 100000)):
+        assert cuking_amd.bytes_per_pair(cuking_amd.words_per_sample(m)) == b
+
+
+@pytest.mark.parametrize("k,shard", [(1, 0), (2, 1), (3, 2), (3, 4)])
+def test_pack_host_matches_oracle(oracle, k, shard):
+    rng = np.random.default_rng(5)
+    n, m = 29, 150
+    geno = random_genotypes(rng, n, m, missing=0.2)
+    col, row = np.nonzero(geno >= 0)
+    alt = geno[col, row].astype(np.int32)
+    perm = rng.permutation(len(row))
+    sm = cuking_amd.Submatrix(n, k, shard)
+    bits = cuking_amd.new_host_bitset(sm, m)
+    cuking_amd.pack_host(sm, bits, row[perm], col[perm], alt[perm])
+    osm = oracle.submatrix(n, k, shard)
+    obits = oracle.new_bitset(osm, m)
+    oracle.pack(osm, obits, row, col, alt)
+    assert bits.shape == obits.shape and np.array_equal(bits, obits)
+
+
+def test_pack_host_concurrent_threads(oracle):
+    """cuking.cu:550-553: files are packed concurrently into one bitset."""
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(6)
+    n, m = 40, 3000
+    geno = random_genotypes(rng, n, m, missing=0.1)
+    col, row = np.nonzero(geno >= 0)
+    alt = geno[col, row].astype(np.int32)
+    perm = rng.permutation(len(row))
+    row, col, alt = row[perm], col[perm], alt[perm]
+    sm = cuking_amd.Submatrix(n)
+    bits = cuking_amd.new_host_bitset(sm, m)
+    chunks = np.array_split(np.arange(len(row)), 16)
+    with ThreadPoolExecutor(8) as ex:
+        list(ex.map(lambda c: cuking_amd.pack_host(sm, bits, row[c], col[c], alt[c]),
+                    chunks))
+    assert np.array_equal(bits, oracle.bitset_from_genotypes(geno))
+
+
+def test_pack_host_errors():
+    sm = cuking_amd.Submatrix(3)
+    bits = cuking_amd.new_host_bitset(sm, 64)
+    with pytest.raises(cuking_amd.CukingError) as e:
+        cuking_amd.pack_host(sm, bits, [0], [0], [3])
+    assert e.value.status == _lib.ERR_FAILED_PRECONDITION
+    assert "Invalid value for n_alt_alleles (3)" in e.value.message  # :699-701
+    with pytest.raises(cuking_amd.CukingError) as e:
+        cuking_amd.pack_host(sm, bits, [64], [0], [0])
+    assert e.value.status == _lib.ERR_INVALID_ARGUMENT
+    cuking_amd.pack_host(sm, bits, [0], [99], [0])  # foreign sample: skipped
+
+
+def test_sort_results_matches_reference_order():
+    rng = np.random.default_rng(0)
+    recs = np.zeros(500, dtype=cuking_amd.KING_RESULT_DTYPE)
+    recs["sample_i"] = rng.integers(0, 6, 500)
+    recs["sample_j"] = rng.integers(0, 6, 500)
+    recs["kin"] = rng.random(500).astype(np.float32)
+    exp = recs[np.lexsort((recs["kin"], recs["sample_j"], recs["sample_i"]))]
+    assert cuking_amd.sort_results(recs.copy()).tobytes() == exp.tobytes()
+
+
+@pytest.mark.parametrize("n,k,shard", [(1, 1, 0), (2, 1, 0), (63, 1, 0), (64, 1, 0),
+                                       (65, 1, 0), (200, 1, 0), (1000, 1, 0),
+                                       (300, 2, 1), (300, 3, 4), (5, 4, 9),
+                                       (2500, 1, 0)])
+def test_tiles_cover_each_pair_exactly_once(n, k, shard):
+    """Host logic of the pair-space tiling (any contiguous split of the tile
+    enumeration is a valid multi-GPU sharding)."""
+    lib = _lib.load()
+    sm = cuking_amd.Submatrix(n, k, shard)
+    tiles = lib.cuking_num_tiles(None, C.byref(sm.c))
+    edge = lib.cuking_tile_samples(None)
+    if sm.NumRows() == 0 or sm.NumCols() == 0:
+        assert tiles == 0
+        return
+    seen = {}
+    rb, re_, cb, ce = (C.c_uint32() for _ in range(4))
+    cover = np.zeros((sm.NumRows(), sm.NumCols()), dtype=np.int32)
+    for t in range(tiles):
+        _lib.check(lib.cuking_tile_bounds(None, C.byref(sm.c), t, C.byref(rb),
+                                          C.byref(re_), C.byref(cb), C.byref(ce)))
+        key = (rb.value, cb.value)
+        assert key not in seen
+        seen[key] = t
+        assert 0 < re_.value - rb.value <= edge and 0 < ce.value - cb.value <= edge
+        cover[rb.value - sm.i_begin:re_.value - sm.i_begin,
+              cb.value - sm.j_begin:ce.value - sm.j_begin] += 1
+    I, J = np.meshgrid(np.arange(sm.i_begin, sm.i_end),
+                       np.arange(sm.j_begin, sm.j_end), indexing="ij")
+    assert np.all(cover[I < J] == 1)       # every pair in exactly one tile
+    assert cover.max() <= 1
+    with pytest.raises(cuking_amd.CukingError):
+        _lib.check(lib.cuking_tile_bounds(None, C.byref(sm.c), tiles, None, None,
+                                          None, None))
+
+
+def test_tile_partition_is_balanced():
+    from cuking_amd.dist import tile_partition
+    for tiles in (0, 1, 7, 8, 12403, 65_800_000):
+        for world in (1, 2, 3, 8):
+            parts = tile_partition(tiles, world)
+            assert parts[0][0] == 0 and parts[-1][1] == tiles
+            assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            sizes = [e - b for b, e in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks behaviour without a GPU")
+def test_no_cpu_fallback_without_gpu():
+    with pytest.raises(cuking_amd.CukingError) as e:
+        cuking_amd.KingContext(0)
+    assert e.value.status == _lib.ERR_DEVICE
+    assert "no CPU path" in e.value.message

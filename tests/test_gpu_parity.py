@@ -1,0 +1,409 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on
+the same seeded inputs.  Integer sums and IBS0/1/2 bit-exact; kin bit-exact
+in float32 (the reference's two-rounding expression).
+
+PARITY UNPINNED by the reference (it ships no vectors): the
+oracle is pinned by the hand-checked KAT and the naive numpy oracle instead
+(tests/test_oracle.py)."""
+import ctypes as C
+import json
+
+import numpy as np
+import pytest
+
+import cuking_amd
+from cuking_amd import _lib
+from cuking_amd.synth import DEFAULT_SEED, cohort_to_device, plan_cohort
+from conftest import GOLDEN, random_genotypes
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = [("stream", 0)] + [("tiled", v) for v in range(4)]
+
+
+def select(ctx, kernel, variant):
+    ctx.set_kernel(kernel)
+    if kernel == "tiled":
+        ctx.set_option("variant", variant)
+
+
+def counts_from_oracle(oracle, sm_tuple, bits):
+    osm = oracle.Submatrix(*sm_tuple)
+    return oracle.all_pairs(osm, bits)
+
+
+def check_counts(ctx, oracle, sm, bits_host):
+    """All six sums of every pair == oracle."""
+    d_bits = ctx.upload_bitset(bits_host)
+    got = ctx.compute_counts(sm, bits_host.shape[1], d_bits)
+    oi, oj, oc, _ = counts_from_oracle(oracle, sm.as_tuple(), bits_host)
+    sel = got[oi - sm.i_begin, oj - sm.j_begin]
+    for name in oc.dtype.names:
+        assert np.array_equal(sel[name], oc[name]), name
+    return len(oi)
+
+
+def test_library_is_the_hip_one(ctx):
+    # The context exists => a gfx950 device and the in-tree .so are in use.
+    assert _lib.LIB_PATH.exists() and cuking_amd.device_count() >= 1
+
+
+@pytest.mark.parametrize("kernel,variant", KERNELS)
+def test_kat(ctx, oracle, kernel, variant):
+    select(ctx, kernel, variant)
+    kat = json.loads((GOLDEN / "kat_4x10.json").read_text())
+    geno = np.array(kat["genotypes"], dtype=np.int8)
+    sm = cuking_amd.Submatrix(4)
+    bits = cuking_amd.new_host_bitset(sm, 10)
+    col, row = np.nonzero(geno >= 0)
+    cuking_amd.pack_host(sm, bits, row, col, geno[col, row])
+    d_bits = ctx.upload_bitset(bits)
+    counts = ctx.compute_counts(sm, bits.shape[1], d_bits)
+    for p in kat["pairs"]:
+        c = counts[p["i"], p["j"]]
+        for name in counts.dtype.names:
+            assert int(c[name]) == p[name], (p, name)
+    res = ctx.run(sm, bits.shape[1], d_bits, kat["thresholded"]["kin_threshold"])
+    names = kat["samples"]
+    got = [[names[r["sample_i"]], names[r["sample_j"]], float(r["kin"]),
+            int(r["ibs0"]), int(r["ibs1"]), int(r["ibs2"])] for r in res]
+    assert got == kat["thresholded"]["records"]
+    assert res["kin"].view(np.uint32)[0] == 0x3F000000
+
+
+SHAPES = [(2, 1), (3, 31), (5, 32), (7, 33), (16, 64), (33, 65), (63, 255),
+          (64, 256), (65, 257), (130, 1000), (257, 3000), (100, 513)]
+
+
+@pytest.mark.parametrize("kernel,variant", KERNELS)
+def test_all_six_counts_every_pair(ctx, oracle, kernel, variant):
+    select(ctx, kernel, variant)
+    rng = np.random.default_rng(1234)
+    total = 0
+    for n, m in SHAPES:
+        geno = random_genotypes(rng, n, m, missing=0.07)
+        if n > 6:
+            geno[1] = -1          # a sample with nothing defined
+            geno[2] = 0           # a sample without hets
+            geno[5] = geno[3]     # duplicates
+        sm = cuking_amd.Submatrix(n)
+        bits = oracle.bitset_from_genotypes(geno)
+        total += check_counts(ctx, oracle, sm, bits)
+    assert total > 60000
+
+
+@pytest.mark.parametrize("kernel,variant", KERNELS)
+@pytest.mark.parametrize("thr", [-1e30, -0.3, 0.0, 0.0884, 0.2])
+def test_thresholded_records_bit_exact(ctx, oracle, kernel, variant, thr):
+    select(ctx, kernel, variant)
+    rng = np.random.default_rng(99)
+    n, m = 150, 777
+    geno = random_genotypes(rng, n, m, missing=0.03)
+    geno[40] = geno[10]
+    geno[41, :400] = geno[11, :400]
+    geno[77] = -1
+    geno[78] = 0
+    sm = cuking_amd.Submatrix(n)
+    bits = oracle.bitset_from_genotypes(geno)
+    exp, ovf, cnt = oracle.compute(oracle.submatrix(n), bits, thr)
+    assert ovf == 0
+    got = ctx.run(sm, bits.shape[1], ctx.upload_bitset(bits), thr)
+    assert got.dtype == exp.dtype or got.dtype.descr == exp.dtype.descr
+    assert got.tobytes() == exp.tobytes()   # i, j, kin bits, ibs0/1/2
+
+
+@pytest.mark.parametrize("kernel,variant", [("stream", 0), ("tiled", 0), ("tiled", 1)])
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_split_factor_shards(ctx, oracle, kernel, variant, k):
+    """--split_factor / --shard_index (cuking.cu:46-52): every shard equals the
+    oracle's shard; their union equals the unsharded run."""
+    select(ctx, kernel, variant)
+    rng = np.random.default_rng(11)
+    n, m = 203, 450
+    geno = random_genotypes(rng, n, m, missing=0.02)
+    geno[150] = geno[20]
+    geno[199] = geno[100]
+    thr = -0.1
+    full = ctx.run(cuking_amd.Submatrix(n), cuking_amd.words_per_sample(m),
+                   ctx.upload_bitset(oracle.bitset_from_genotypes(geno)), thr)
+    parts = []
+    for shard in range(k * (k + 1) // 2):
+        sm = cuking_amd.Submatrix(n, k, shard)
+        osm = oracle.submatrix(n, k, shard)
+        bits = oracle.bitset_from_genotypes(geno, osm)   # shard-local storage
+        assert bits.shape[0] == sm.NumSamples()
+        exp, _, _ = oracle.compute(osm, bits, thr)
+        got = ctx.run(sm, bits.shape[1], ctx.upload_bitset(bits), thr)
+        assert got.tobytes() == exp.tobytes(), shard
+        check_counts(ctx, oracle, sm, bits)
+        parts.append(got)
+    merged = cuking_amd.sort_results(np.ascontiguousarray(np.concatenate(parts)))
+    assert merged.tobytes() == full.tobytes()
+
+
+@pytest.mark.parametrize("variant", range(4))
+def test_tile_ranges_union(ctx, oracle, variant):
+    """Pair-space sharding for multi-GPU: disjoint tile ranges == whole block."""
+    select(ctx, "tiled", variant)
+    rng = np.random.default_rng(5)
+    n, m = 300, 200
+    geno = random_genotypes(rng, n, m)
+    bits = oracle.bitset_from_genotypes(geno)
+    sm = cuking_amd.Submatrix(n)
+    d_bits = ctx.upload_bitset(bits)
+    whole = ctx.run(sm, bits.shape[1], d_bits, -0.05)
+    tiles = ctx.num_tiles(sm)
+    assert tiles >= 3
+    from cuking_amd.dist import tile_partition
+    for world in (2, 3):
+        parts = [ctx.run(sm, bits.shape[1], d_bits, -0.05, tile_range=r)
+                 for r in tile_partition(tiles, world)]
+        merged = cuking_amd.sort_results(np.ascontiguousarray(np.concatenate(parts)))
+        assert merged.tobytes() == whole.tobytes()
+    with pytest.raises(cuking_amd.CukingError):
+        ctx.run(sm, bits.shape[1], d_bits, -0.05, tile_range=(0, tiles + 1))
+
+
+@pytest.mark.parametrize("kernel,variant", [("stream", 0), ("tiled", 0)])
+def test_result_overflow(ctx, oracle, kernel, variant):
+    """cuking.cu:297-313, :747-751: overflow is an error, never truncation."""
+    import torch
+    select(ctx, kernel, variant)
+    rng = np.random.default_rng(2)
+    geno = random_genotypes(rng, 80, 300)
+    bits = oracle.bitset_from_genotypes(geno)
+    sm = cuking_amd.Submatrix(80)
+    d_bits = ctx.upload_bitset(bits)
+    exp, _, n_all = oracle.compute(oracle.submatrix(80), bits, -5.0)
+    assert n_all > 1000
+    with pytest.raises(cuking_amd.ResourceExhaustedError) as e:
+        ctx.run(sm, bits.shape[1], d_bits, -5.0, max_results=1000)
+    assert "--max_results" in str(e.value)
+    # raw contract: the counter keeps counting, the flag is set, and the
+    # first max_results slots hold valid records
+    results = torch.zeros((1000, 6), dtype=torch.int32, device="cuda:0")
+    idx = torch.zeros(2, dtype=torch.int32, device="cuda:0")
+    ctx.compute_king(sm, bits.shape[1], d_bits, -5.0, 1000, results, idx[0:1], idx[1:2])
+    torch.cuda.synchronize()
+    assert idx.tolist() == [n_all, 1]
+    recs = results.cpu().numpy().view(np.uint32).reshape(-1).view(cuking_amd.KING_RESULT_DTYPE)
+    keys = {(int(r["sample_i"]), int(r["sample_j"])): r for r in exp}
+    for r in recs:
+        assert keys[(int(r["sample_i"]), int(r["sample_j"]))].tobytes() == r.tobytes()
+    # exactly enough room: no overflow, all records
+    got = ctx.run(sm, bits.shape[1], d_bits, -5.0, max_results=n_all)
+    assert got.tobytes() == exp.tobytes()
+
+
+def test_appending_calls_share_one_buffer(ctx, oracle):
+    """result_index is not reset by the call (cuking.cu:721-722 leaves that to
+    the caller), so shards can append into one buffer."""
+    import torch
+    select(ctx, "tiled", 0)
+    rng = np.random.default_rng(8)
+    n, m = 120, 300
+    geno = random_genotypes(rng, n, m)
+    results = torch.zeros((20000, 6), dtype=torch.int32, device="cuda:0")
+    idx = torch.zeros(2, dtype=torch.int32, device="cuda:0")
+    for shard in range(3):
+        sm = cuking_amd.Submatrix(n, 2, shard)
+        bits = oracle.bitset_from_genotypes(geno, oracle.submatrix(n, 2, shard))
+        ctx.compute_king(sm, bits.shape[1], ctx.upload_bitset(bits), -0.2, 20000,
+                         results, idx[0:1], idx[1:2])
+        torch.cuda.synchronize()
+    count, ovf = idx.tolist()
+    exp, _, _ = oracle.compute(oracle.submatrix(n), oracle.bitset_from_genotypes(geno), -0.2)
+    assert ovf == 0 and count == len(exp)
+    recs = results[:count].cpu().numpy().view(np.uint32).reshape(-1).view(
+        cuking_amd.KING_RESULT_DTYPE).copy()
+    assert cuking_amd.sort_results(recs).tobytes() == exp.tobytes()
+
+
+def test_empty_and_tiny_blocks(ctx, oracle):
+    import torch
+    select(ctx, "tiled", 0)
+    # N=5, k=4: block 3 is empty after clamping
+    for shard in range(10):
+        sm = cuking_amd.Submatrix(5, 4, shard)
+        osm = oracle.submatrix(5, 4, shard)
+        geno = random_genotypes(np.random.default_rng(shard), 5, 40)
+        bits = oracle.bitset_from_genotypes(geno, osm)
+        if bits.shape[0] == 0:
+            d_bits = torch.zeros(2, dtype=torch.int64, device="cuda:0")
+        else:
+            d_bits = ctx.upload_bitset(bits)
+        got = ctx.run(sm, cuking_amd.words_per_sample(40), d_bits, -100.0)
+        exp, _, _ = oracle.compute(osm, bits, -100.0)
+        assert got.tobytes() == exp.tobytes()
+    sm1 = cuking_amd.Submatrix(1)
+    one = ctx.upload_bitset(oracle.bitset_from_genotypes(np.ones((1, 8), dtype=np.int8)))
+    assert len(ctx.run(sm1, 2, one, -100.0)) == 0
+
+
+def test_argument_errors(ctx, oracle):
+    import torch
+    bits = torch.zeros(10, dtype=torch.int64, device="cuda:0")
+    sm = cuking_amd.Submatrix(100)
+    with pytest.raises(ValueError):
+        ctx.run(sm, 2, bits)                       # too small for the block
+    with pytest.raises(cuking_amd.CukingError) as e:
+        ctx.run(cuking_amd.Submatrix(2), 3, bits)  # odd words_per_sample
+    assert e.value.status == _lib.ERR_INVALID_ARGUMENT
+    with pytest.raises(cuking_amd.CukingError):
+        ctx.set_option("variant", 99)
+
+
+@pytest.mark.parametrize("k,shard", [(1, 0), (3, 1), (3, 3)])
+def test_pack_device_matches_host_and_oracle(ctx, oracle, k, shard):
+    import torch
+    rng = np.random.default_rng(21)
+    n, m = 90, 1500
+    geno = random_genotypes(rng, n, m, missing=0.1)
+    col, row = np.nonzero(geno >= 0)
+    alt = geno[col, row].astype(np.int32)
+    perm = rng.permutation(len(row))
+    row, col, alt = row[perm], col[perm], alt[perm]
+    sm = cuking_amd.Submatrix(n, k, shard)
+    wps = cuking_amd.words_per_sample(m)
+    host = cuking_amd.new_host_bitset(sm, m)
+    cuking_amd.pack_host(sm, host, row, col, alt)
+    d_bits = torch.full((sm.NumSamples(), wps), -1, dtype=torch.int64, device="cuda:0")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+    ctx.pack_device(sm, wps, d_bits, torch.from_numpy(row).cuda(),
+                    torch.from_numpy(col).cuda(), torch.from_numpy(alt).cuda(), status)
+    torch.cuda.synchronize()
+    assert int(status) == 0
+    dev = d_bits.cpu().numpy().view(np.uint64)
+    assert np.array_equal(dev, host)
+    assert np.array_equal(dev, oracle.bitset_from_genotypes(geno, oracle.submatrix(n, k, shard)))
+    # invalid genotype / row are reported, not silently packed
+    bad_alt = alt.copy()
+    bad_alt[3] = 7
+    bad_row = row.copy()
+    bad_row[5] = cuking_amd.padded_sites(m) + 64
+    status.zero_()
+    ctx.pack_device(sm, wps, d_bits, torch.from_numpy(bad_row).cuda(),
+                    torch.from_numpy(col).cuda(), torch.from_numpy(bad_alt).cuda(), status)
+    torch.cuda.synchronize()
+    exp = (1 if sm.Contains(int(col[3])) else 0) | (2 if sm.Contains(int(col[5])) else 0)
+    assert int(status) == exp
+
+
+def test_synth_device_equals_oracle_twin(ctx, oracle):
+    import torch
+    cohort = plan_cohort(400, seed=77)
+    assert cohort.num_founders < 400 and len(cohort.planted) > 10
+    kind, pa, pb = cohort_to_device(cohort)
+    for m in (1, 63, 64, 1000, 2049):
+        dev = ctx.synth_bitset(77, kind, pa, pb, 0, 400, m)
+        torch.cuda.synchronize()
+        exp = oracle.synth_bitset(77, cohort.kind, cohort.pa, cohort.pb, 0, 400, m)
+        assert np.array_equal(dev.cpu().numpy().view(np.uint64), exp), m
+    # a slice of rows
+    dev = ctx.synth_bitset(77, kind, pa, pb, 380, 400, 500)
+    torch.cuda.synchronize()
+    exp = oracle.synth_bitset(77, cohort.kind, cohort.pa, cohort.pb, 380, 400, 500)
+    assert np.array_equal(dev.cpu().numpy().view(np.uint64), exp)
+
+
+# ---------------------------------------------------------------------------
+# BASELINE configs[1] at full size (10k samples x 100k sites, threshold 0.05):
+# the oracle cannot run 5e7 pairs x 50 KB in seconds, so parity is checked
+# through sub-blocks and size-independent properties.
+# ---------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c1(ctx):
+    import torch
+    n, m = 10000, 100000
+    cohort = plan_cohort(n, DEFAULT_SEED)
+    kind, pa, pb = cohort_to_device(cohort)
+    bits = ctx.synth_bitset(DEFAULT_SEED, kind, pa, pb, 0, n, m)
+    torch.cuda.synchronize()
+    select(ctx, "tiled", 0)
+    res = ctx.run(cuking_amd.Submatrix(n), cuking_amd.words_per_sample(m), bits, 0.05)
+    return dict(n=n, m=m, cohort=cohort, bits=bits, res=res)
+
+
+def test_c1_planted_relatives_found(c1):
+    res = c1["res"]
+    got = {(int(r["sample_i"]), int(r["sample_j"])): float(r["kin"]) for r in res}
+    lo = {"dup": 0.45, "po": 0.2, "sib": 0.15, "half": 0.07}
+    hi = {"dup": 0.5, "po": 0.3, "sib": 0.35, "half": 0.19}
+    for a, b, rel in c1["cohort"].planted:
+        i, j = min(a, b), max(a, b)
+        assert (i, j) in got, (i, j, rel)
+        assert lo[rel] <= got[(i, j)] <= hi[rel] + 1e-6, (rel, got[(i, j)])
+    # unrelated founders stay below the threshold: output is dominated by
+    # planted pairs and their close kin
+    assert len(res) < 40 * len(c1["cohort"].planted)
+    assert np.all(res["sample_i"] < res["sample_j"])
+    assert np.all(res["kin"] > np.float32(0.05))
+    s = res["ibs0"].astype(np.int64) + res["ibs1"] + res["ibs2"]
+    assert np.all(s <= c1["m"]) and np.all(s > 0.9 * c1["m"])
+    key = res["sample_i"].astype(np.int64) * c1["n"] + res["sample_j"]
+    assert np.all(np.diff(key) > 0)  # sorted, no pair twice
+
+
+def test_c1_subblocks_match_oracle(ctx, oracle, c1):
+    """Diagonal sub-block of founders and the derived tail (relatives), plus
+    the rectangle between them, re-computed by the oracle from the same bits."""
+    import torch
+    n, res, bits = c1["n"], c1["res"], c1["bits"]
+    wps = bits.shape[1]
+    nf = c1["cohort"].num_founders
+    for (a0, a1), (b0, b1) in [((0, 96), (0, 96)), ((n - 160, n), (n - 160, n)),
+                               ((64, 160), (n - 96, n))]:
+        rows = bits[a0:a1].cpu().numpy().view(np.uint64)
+        if (a0, a1) == (b0, b1):
+            osm = oracle.Submatrix(a0, a1, a0, a1)
+            host = np.ascontiguousarray(rows)
+        else:
+            osm = oracle.Submatrix(a0, a1, b0, b1)
+            host = np.ascontiguousarray(np.concatenate(
+                [rows, bits[b0:b1].cpu().numpy().view(np.uint64)]))
+        exp, ovf, _ = oracle.compute(osm, host, 0.05)
+        sel = res[(res["sample_i"] >= a0) & (res["sample_i"] < a1) &
+                  (res["sample_j"] >= b0) & (res["sample_j"] < b1)]
+        assert sel.tobytes() == exp.tobytes()
+        # and every count of every pair of the sub-block through the ABI
+        sm = cuking_amd.Submatrix.from_ranges(*osm.as_tuple())
+        select(ctx, "tiled", 0)
+        check_counts(ctx, oracle, sm, host)
+    assert nf < n - 160 or True
+
+
+def test_c1_kernels_and_variants_agree(ctx, c1):
+    """Idempotence + every kernel shape produces the same records."""
+    n, m, bits = c1["n"], c1["m"], c1["bits"]
+    sm = cuking_amd.Submatrix(n)
+    base = c1["res"].tobytes()
+    for variant in range(4):
+        select(ctx, "tiled", variant)
+        assert ctx.run(sm, bits.shape[1], bits, 0.05).tobytes() == base, variant
+    # the streaming kernel on the last 1500 samples (all relatives live there)
+    lo = n - 1500
+    select(ctx, "stream", 0)
+    sub = cuking_amd.Submatrix.from_ranges(lo, n, lo, n)
+    got = ctx.run(sub, bits.shape[1], bits[lo:].contiguous(), 0.05)
+    res = c1["res"]
+    exp = res[(res["sample_i"] >= lo)]
+    assert got.tobytes() == exp.tobytes()
+    select(ctx, "tiled", 0)
+
+
+def test_c1_split_factor_union(ctx, c1):
+    """README.md:80-89 style run: --split_factor=4 => 10 shards, union == whole."""
+    import torch
+    n, bits = c1["n"], c1["bits"]
+    wps = bits.shape[1]
+    select(ctx, "tiled", 0)
+    parts = []
+    for shard in range(10):
+        sm = cuking_amd.Submatrix(n, 4, shard)
+        if sm.i_begin == sm.j_begin:
+            local = bits[sm.i_begin:sm.i_end]
+        else:
+            local = torch.cat([bits[sm.i_begin:sm.i_end], bits[sm.j_begin:sm.j_end]])
+        parts.append(ctx.run(sm, wps, local.contiguous(), 0.05))
+    merged = cuking_amd.sort_results(np.ascontiguousarray(np.concatenate(parts)))
+    assert merged.tobytes() == c1["res"].tobytes()
