@@ -103,6 +103,14 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m cuking_amd.build` "
             "(hipcc, gfx950).  cuking_amd has no CPU fallback.")
+    # torch ships its own libamdhip64.so (same SONAME as /opt/rocm's).  A
+    # process must hold exactly one HIP runtime, so when torch is going to be
+    # used for device memory it has to be loaded first; our library then binds
+    # to that copy.  (A host without torch, e.g. the C++ CLI, gets /opt/rocm's.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a symbol
