@@ -34,8 +34,13 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CU x 4 SIMD-32 x 2.4 GHz
-VALU_OPS_PER_PAIR_WORD = 10     # king_kernels.hip: ops per pair per 32 sites
+NOMINAL_CLOCK_HZ = 2.4e9        # MI355X_MICROARCH.md: max clock
+NUM_SIMDS = 256 * 4
+VALU_OPS_PER_PAIR_WORD = 10     # king_kernels.hip: 5 logic + 5 v_bcnt per pair per 32 sites
+# Measured on MI355X (tools/micro/valu_mix.hip, profiles/r01_valu_microbench.txt):
+# that 5+5 instruction mix issues at 3.39 cycles per wave64 instruction per SIMD
+# (v_and/v_bitop3 ~2.7, v_bcnt_u32_b32 ~4.25), i.e. 33.9 cycles per pair-word.
+VALU_FLOOR_CYCLES_PER_PAIR_WORD = 33.9
 
 
 def parse_args():
@@ -52,18 +57,23 @@ def parse_args():
     ap.add_argument("--band-rows", type=int, default=-1)
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target CPU-baseline time (0 disables it)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="OpenMP threads of the CPU baseline (0 = min(16, available))")
     ap.add_argument("--seed", type=int, default=20240229)
     return ap.parse_args()
 
 
-def cpu_baseline(host_bits_fn, wps, gpu_records, thr, target_seconds):
+def cpu_baseline(host_bits_fn, wps, gpu_records, thr, target_seconds, max_samples,
+                 cpu_threads=0):
     """Times the oracle (oracle/king_oracle.c, -march=native, OpenMP over rows)
     on a leading sub-block of the SAME cohort, and checks the GPU's records for
     that sub-block against it.  Test-infrastructure use only."""
     import tempfile
     import numpy as np
     from oracle import pyoracle
-    threads = len(os.sched_getaffinity(0))
+    # The GPU box's CPU share for one GPU is 16 hardware threads (its 8 GPUs
+    # share the host); --cpu-threads overrides.
+    threads = cpu_threads or min(16, len(os.sched_getaffinity(0)))
     out_dir = Path(tempfile.mkdtemp(prefix="cuking_oracle_"))
     lib = pyoracle.load(native=True, out_dir=out_dir)
     os.environ.setdefault("OMP_PROC_BIND", "true")
@@ -85,7 +95,7 @@ def cpu_baseline(host_bits_fn, wps, gpu_records, thr, target_seconds):
 
     pairs, dt, _ = run(256)                      # calibration
     rate = pairs / dt
-    s = int(min(4096, max(256, math.sqrt(2 * rate * target_seconds))))
+    s = int(min(max_samples, max(256, math.sqrt(2 * rate * target_seconds))))
     pairs, dt, res = run(s)
     sel = gpu_records[(gpu_records["sample_j"] < s)]
     if sel.tobytes() != res.tobytes():
@@ -237,13 +247,18 @@ def main():
             "note": "algorithmic bytes (2 samples x words_per_sample x 8 B per pair) / "
                     "measured kernel time; the tiled kernel re-uses operands from LDS and "
                     "registers, so this exceeds 1.0 of HBM peak by design (it is VALU-bound)",
-            "valu": {
-                "achieved_lane_ops_per_s": launch_pairs * wps * VALU_OPS_PER_PAIR_WORD / (king_ms * 1e-3) if king_ms > 0 else 0.0,
-                "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
-            },
             "prepare_ms": timing.prepare_ms / max(timing.prepare_launches, 1),
         }
-        roofline["valu"]["frac"] = roofline["valu"]["achieved_lane_ops_per_s"] / VALU_PEAK_LANE_OPS
+        # VALU view: wave64 issue cycles one SIMD spends per pair and 32-site
+        # word (at the nominal clock) against the measured floor for this mix.
+        cyc = (king_ms * 1e-3 * NOMINAL_CLOCK_HZ * NUM_SIMDS * 64 /
+               (launch_pairs * wps)) if king_ms > 0 else 0.0
+        roofline["valu"] = {
+            "ops_per_pair_word": VALU_OPS_PER_PAIR_WORD,
+            "achieved_cycles_per_pair_word": cyc,
+            "floor_cycles_per_pair_word": VALU_FLOOR_CYCLES_PER_PAIR_WORD,
+            "frac": VALU_FLOOR_CYCLES_PER_PAIR_WORD / cyc if cyc else 0.0,
+        }
         out = {
             "metric": "sample-pairs/s (all-pairs KING)", "value": value,
             "unit": "sample-pairs/s", "n_gpus": world, "steps": args.steps,
@@ -260,7 +275,8 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             def host_bits(s):
                 return np.ascontiguousarray(bits[:s].cpu().numpy().view(np.uint64))
-            out["cpu_baseline"] = cpu_baseline(host_bits, wps, recs, thr, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(host_bits, wps, recs, thr, args.cpu_seconds,
+                                               n, args.cpu_threads)
         else:
             out["cpu_baseline"] = None
     if world > 1:
