@@ -1,0 +1,386 @@
+// `cuking` for MI355X: drop-in for the reference binary's Parquet-in /
+// Parquet-out path (cuking.cu:435-895) -- same flags, same input layout, same
+// output file name, schema and ordering -- with the device work behind the
+// C ABI of include/cuking_amd.h.  C++ host only; no GPU code in this file.
+//
+// Differences from the reference, all at the storage edge: URIs are local
+// paths (or file://) because no GCS client exists in this image; gs:// is
+// rejected with a clear error.  Everything after the bytes are read is the
+// same pipeline: metadata -> Submatrix -> all-ones bitset -> parallel Parquet
+// decode + pack -> kernel -> overflow check -> sort -> Snappy Parquet.
+#include <dirent.h>
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "cuking_amd.h"
+#include "flags.h"
+#include "metadata.h"
+#include "parquet_io.h"
+#include "thread_pool.h"
+
+namespace {
+
+using cuking_host::Flags;
+
+struct Status {
+  std::string code;  // "" = OK; otherwise absl-style code name
+  std::string message;
+  bool ok() const { return code.empty(); }
+  static Status Ok() { return {}; }
+};
+
+Status InvalidArgument(std::string m) { return {"INVALID_ARGUMENT", std::move(m)}; }
+Status FailedPrecondition(std::string m) { return {"FAILED_PRECONDITION", std::move(m)}; }
+Status ResourceExhausted(std::string m) { return {"RESOURCE_EXHAUSTED", std::move(m)}; }
+Status Unknown(std::string m) { return {"UNKNOWN", std::move(m)}; }
+
+Status FromAbi(cuking_status st) {
+  if (st == CUKING_OK) return Status::Ok();
+  const std::string msg = cuking_last_error();
+  switch (st) {
+    case CUKING_ERR_INVALID_ARGUMENT: return InvalidArgument(msg);
+    case CUKING_ERR_FAILED_PRECONDITION: return FailedPrecondition(msg);
+    case CUKING_ERR_RESOURCE_EXHAUSTED: return ResourceExhausted(msg);
+    case CUKING_ERR_OUT_OF_MEMORY: return {"RESOURCE_EXHAUSTED", msg};
+    default: return {"INTERNAL", msg};
+  }
+}
+
+#define RETURN_IF_ERROR(expr)          \
+  do {                                 \
+    Status _s = (expr);                \
+    if (!_s.ok()) return _s;           \
+  } while (0)
+
+class StopWatch {  // cuking.cu:325-337
+ public:
+  double ElapsedAndReset() {
+    const auto now = std::chrono::steady_clock::now();
+    const double s = std::chrono::duration<double>(now - last_).count();
+    last_ = now;
+    return s;
+  }
+
+ private:
+  std::chrono::steady_clock::time_point last_ = std::chrono::steady_clock::now();
+};
+
+void Done(StopWatch *sw) {
+  std::cout << " (" << std::fixed << std::setprecision(3) << sw->ElapsedAndReset()
+            << "s)" << std::endl;
+}
+
+// The reference only takes gs:// URIs (cuking.cu:340-353).  Here: local.
+Status ResolveUri(const std::string &uri, std::string *path) {
+  if (uri.rfind("gs://", 0) == 0)
+    return InvalidArgument("Unsupported URI: " + uri +
+                           " (this build has no GCS client; pass a local "
+                           "directory or file:// URI)");
+  *path = uri.rfind("file://", 0) == 0 ? uri.substr(7) : uri;
+  while (path->size() > 1 && path->back() == '/') path->pop_back();
+  if (path->empty()) return InvalidArgument("Incomplete URI " + uri);
+  return Status::Ok();
+}
+
+// Non-recursive listing of *.parquet (cuking.cu:529-545: the "/" delimiter
+// skips Spark's _temporary/ folders).
+Status ListParquetFiles(const std::string &dir,
+                        std::vector<std::pair<std::string, size_t>> *files) {
+  DIR *d = opendir(dir.c_str());
+  if (d == nullptr)
+    return FailedPrecondition("Cannot list " + dir + ": " + strerror(errno));
+  while (dirent *e = readdir(d)) {
+    const std::string name = e->d_name;
+    const std::string suffix = ".parquet";
+    if (name.size() < suffix.size() ||
+        name.compare(name.size() - suffix.size(), suffix.size(), suffix) != 0)
+      continue;
+    const std::string full = dir + "/" + name;
+    struct stat st;
+    if (stat(full.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) continue;
+    files->emplace_back(full, (size_t)st.st_size);
+  }
+  closedir(d);
+  std::sort(files->begin(), files->end());
+  return Status::Ok();
+}
+
+Status MakeDirs(const std::string &path) {
+  std::string cur;
+  std::istringstream parts(path);
+  std::string part;
+  if (!path.empty() && path[0] == '/') cur = "/";
+  while (std::getline(parts, part, '/')) {
+    if (part.empty()) continue;
+    cur += part + "/";
+    if (mkdir(cur.c_str(), 0777) != 0 && errno != EEXIST)
+      return Unknown("Cannot create " + cur + ": " + strerror(errno));
+  }
+  return Status::Ok();
+}
+
+uint64_t CeilMiB(uint64_t bytes) { return (bytes + (1u << 20) - 1) >> 20; }
+
+struct DeviceBuffers {
+  cuking_ctx *ctx = nullptr;
+  void *host_bits = nullptr;
+  void *d_bits = nullptr, *d_results = nullptr, *d_counters = nullptr;
+  ~DeviceBuffers() {
+    if (ctx == nullptr) return;
+    if (host_bits) cuking_host_free(ctx, host_bits);
+    if (d_bits) cuking_device_free(ctx, d_bits);
+    if (d_results) cuking_device_free(ctx, d_results);
+    if (d_counters) cuking_device_free(ctx, d_counters);
+    cuking_ctx_destroy(ctx);
+  }
+};
+
+Status Run(const Flags &flags) {
+  {
+    const std::string err = cuking_host::ValidateFlags(flags);
+    if (!err.empty()) return InvalidArgument(err);
+  }
+  std::string input_dir, output_dir;
+  RETURN_IF_ERROR(ResolveUri(flags.input_uri, &input_dir));
+  RETURN_IF_ERROR(ResolveUri(flags.output_uri, &output_dir));
+
+  StopWatch sw;
+  std::cout << "Reading metadata..." << std::flush;
+  cuking_host::Metadata metadata;
+  {
+    const std::string err =
+        cuking_host::ReadMetadataFile(input_dir + "/metadata.json", &metadata);
+    if (!err.empty()) return FailedPrecondition(err);
+  }
+  if (metadata.samples.size() > 0xFFFFFFFFull)
+    return FailedPrecondition("too many samples");
+  const uint32_t num_samples = (uint32_t)metadata.samples.size();
+  const uint32_t words_per_sample = cuking_words_per_sample(metadata.num_sites);
+  Done(&sw);
+
+  cuking_submatrix sm;  // cuking.cu:505
+  RETURN_IF_ERROR(FromAbi(cuking_submatrix_init(&sm, num_samples, flags.split_factor,
+                                                flags.shard_index)));
+
+  const size_t bit_set_words =
+      (size_t)words_per_sample * cuking_submatrix_num_samples(&sm);
+  const size_t bit_set_bytes = bit_set_words * sizeof(uint64_t);
+  const bool dump_only = !flags.dump_bitset.empty();
+  const bool pack_on_device = flags.pack == "device" && !dump_only;
+
+  DeviceBuffers buf;
+  std::vector<uint64_t> dump_bits;  // --dump_bitset: plain host memory, no GPU
+  std::cout << "Allocating " << CeilMiB(bit_set_bytes)
+            << " MiB of memory for bit set..." << std::flush;
+  if (dump_only) {
+    dump_bits.assign(bit_set_words, ~0ull);
+  } else {
+    RETURN_IF_ERROR(FromAbi(cuking_ctx_create(flags.device, &buf.ctx)));
+    RETURN_IF_ERROR(FromAbi(cuking_ctx_set_kernel(
+        buf.ctx,
+        flags.kernel == "stream" ? CUKING_KERNEL_STREAM : CUKING_KERNEL_TILED)));
+    RETURN_IF_ERROR(FromAbi(cuking_device_alloc(buf.ctx, bit_set_bytes, &buf.d_bits)));
+    if (pack_on_device) {
+      RETURN_IF_ERROR(FromAbi(
+          cuking_memset_async(buf.ctx, buf.d_bits, 0xFF, bit_set_bytes, nullptr)));
+    } else {
+      // Page-locked staging buffer; all ones = everything missing
+      // (cuking.cu:520-523).
+      RETURN_IF_ERROR(FromAbi(cuking_host_alloc(buf.ctx, bit_set_bytes, &buf.host_bits)));
+      if (bit_set_bytes) memset(buf.host_bits, 0xFF, bit_set_bytes);
+    }
+  }
+  uint64_t *host_bits =
+      dump_only ? dump_bits.data() : static_cast<uint64_t *>(buf.host_bits);
+  Done(&sw);
+
+  std::cout << "Listing input files..." << std::flush;
+  std::vector<std::pair<std::string, size_t>> input_files;
+  RETURN_IF_ERROR(ListParquetFiles(input_dir, &input_files));
+  Done(&sw);
+  if (input_files.empty()) return FailedPrecondition("No input files found");  // :542-544
+  std::cout << "Found " << input_files.size() << " input files." << std::endl;
+
+  std::cout << "Processing Parquet tables..." << std::flush;
+  std::atomic<size_t> num_processed(0), num_triples(0);
+  std::mutex device_mu;  // the context is single-threaded
+  uint32_t *d_pack_status = nullptr;
+  if (pack_on_device) {
+    RETURN_IF_ERROR(FromAbi(cuking_device_alloc(buf.ctx, sizeof(uint32_t),
+                                                reinterpret_cast<void **>(&d_pack_status))));
+    RETURN_IF_ERROR(FromAbi(
+        cuking_memset_async(buf.ctx, d_pack_status, 0, sizeof(uint32_t), nullptr)));
+  }
+  const std::string pack_error = cuking_host::ParallelFor(
+      flags.num_reader_threads, 0, input_files.size(), [&](size_t f) -> std::string {
+        cuking_host::Triples t;
+        std::string err = cuking_host::ReadTriples(input_files[f].first, &t);
+        if (!err.empty()) return "FAILED_PRECONDITION\n" + err;
+        const size_t n = t.row_idx.size();
+        if (!pack_on_device) {
+          if (cuking_pack_host(&sm, words_per_sample, host_bits, t.row_idx.data(),
+                               t.col_idx.data(), t.n_alt_alleles.data(), n) != CUKING_OK)
+            return std::string("FAILED_PRECONDITION\n") + cuking_last_error() + " in " +
+                   input_files[f].first;
+        } else if (n > 0) {
+          std::lock_guard<std::mutex> lock(device_mu);
+          void *d_row = nullptr, *d_col = nullptr, *d_alt = nullptr;
+          auto release = [&]() {
+            cuking_device_free(buf.ctx, d_row);
+            cuking_device_free(buf.ctx, d_col);
+            cuking_device_free(buf.ctx, d_alt);
+          };
+          bool ok =
+              cuking_device_alloc(buf.ctx, n * 8, &d_row) == CUKING_OK &&
+              cuking_device_alloc(buf.ctx, n * 8, &d_col) == CUKING_OK &&
+              cuking_device_alloc(buf.ctx, n * 4, &d_alt) == CUKING_OK &&
+              cuking_copy_to_device(buf.ctx, d_row, t.row_idx.data(), n * 8, nullptr) == CUKING_OK &&
+              cuking_copy_to_device(buf.ctx, d_col, t.col_idx.data(), n * 8, nullptr) == CUKING_OK &&
+              cuking_copy_to_device(buf.ctx, d_alt, t.n_alt_alleles.data(), n * 4, nullptr) == CUKING_OK &&
+              cuking_pack_device(buf.ctx, &sm, words_per_sample,
+                                 static_cast<uint64_t *>(buf.d_bits),
+                                 static_cast<int64_t *>(d_row), static_cast<int64_t *>(d_col),
+                                 static_cast<int32_t *>(d_alt), n, d_pack_status,
+                                 nullptr) == CUKING_OK &&
+              cuking_stream_synchronize(buf.ctx, nullptr) == CUKING_OK;
+          const std::string msg = ok ? "" : cuking_last_error();
+          release();
+          if (!ok) return "INTERNAL\n" + msg;
+        }
+        num_triples += n;
+        if ((++num_processed & 1023) == 0) std::cout << "." << std::flush;  // :705-708
+        return "";
+      });
+  if (!pack_error.empty()) {
+    const size_t nl = pack_error.find('\n');
+    return {pack_error.substr(0, nl), pack_error.substr(nl + 1)};
+  }
+  if (dump_only) {
+    Done(&sw);
+    FILE *f = fopen(flags.dump_bitset.c_str(), "wb");
+    if (f == nullptr) return Unknown("Cannot write " + flags.dump_bitset);
+    const size_t wrote = fwrite(dump_bits.data(), sizeof(uint64_t), bit_set_words, f);
+    fclose(f);
+    if (wrote != bit_set_words) return Unknown("Short write to " + flags.dump_bitset);
+    std::cout << "Dumped " << bit_set_words << " words (" << num_triples.load()
+              << " triples) to " << flags.dump_bitset << std::endl;
+    return Status::Ok();
+  }
+  if (pack_on_device) {
+    uint32_t pack_status = 0;
+    RETURN_IF_ERROR(FromAbi(cuking_copy_to_host(buf.ctx, &pack_status, d_pack_status,
+                                                sizeof(uint32_t), nullptr)));
+    RETURN_IF_ERROR(FromAbi(cuking_stream_synchronize(buf.ctx, nullptr)));
+    cuking_device_free(buf.ctx, d_pack_status);
+    if (pack_status & 1u)
+      return FailedPrecondition("Invalid value for n_alt_alleles encountered");
+    if (pack_status & 2u)
+      return InvalidArgument("row_idx outside the padded sites encountered");
+  } else {
+    RETURN_IF_ERROR(FromAbi(cuking_copy_to_device(buf.ctx, buf.d_bits, buf.host_bits,
+                                                  bit_set_bytes, nullptr)));
+    RETURN_IF_ERROR(FromAbi(cuking_stream_synchronize(buf.ctx, nullptr)));
+    cuking_host_free(buf.ctx, buf.host_bits);
+    buf.host_bits = nullptr;
+  }
+  Done(&sw);
+
+  const uint32_t max_results = flags.max_results;
+  std::cout << "Allocating " << CeilMiB((uint64_t)max_results * sizeof(cuking_result))
+            << " MiB of memory for results..." << std::flush;
+  RETURN_IF_ERROR(FromAbi(cuking_device_alloc(
+      buf.ctx, (size_t)max_results * sizeof(cuking_result), &buf.d_results)));
+  RETURN_IF_ERROR(FromAbi(cuking_device_alloc(buf.ctx, 2 * sizeof(uint32_t), &buf.d_counters)));
+  RETURN_IF_ERROR(FromAbi(
+      cuking_memset_async(buf.ctx, buf.d_counters, 0, 2 * sizeof(uint32_t), nullptr)));
+  Done(&sw);
+
+  const uint32_t num_rows = cuking_submatrix_num_rows(&sm);
+  const uint32_t num_cols = cuking_submatrix_num_cols(&sm);
+  std::cout << "Running KING HIP kernel for " << num_rows << " x " << num_cols
+            << " matrix..." << std::flush;
+  uint32_t *d_counters = static_cast<uint32_t *>(buf.d_counters);
+  RETURN_IF_ERROR(FromAbi(cuking_compute_king(
+      buf.ctx, &sm, words_per_sample, static_cast<uint64_t *>(buf.d_bits),
+      flags.kin_threshold, max_results, static_cast<cuking_result *>(buf.d_results),
+      d_counters, d_counters + 1, nullptr)));
+  uint32_t counters[2] = {0, 0};
+  RETURN_IF_ERROR(FromAbi(cuking_copy_to_host(buf.ctx, counters, d_counters,
+                                              sizeof(counters), nullptr)));
+  RETURN_IF_ERROR(FromAbi(cuking_stream_synchronize(buf.ctx, nullptr)));  // errors surface here
+  const double kernel_seconds = sw.ElapsedAndReset();
+  std::cout << " (" << std::fixed << std::setprecision(3) << kernel_seconds << "s)"
+            << std::endl;
+
+  if (counters[1] != 0)  // cuking.cu:747-751
+    return ResourceExhausted(
+        "Could not store all results: try increasing the --max_results parameter.");
+
+  const uint32_t num_results = counters[0];
+  std::cout << "Processing " << num_results << " results..." << std::flush;
+  std::vector<cuking_result> results(num_results);
+  RETURN_IF_ERROR(FromAbi(cuking_copy_to_host(buf.ctx, results.data(), buf.d_results,
+                                              (size_t)num_results * sizeof(cuking_result),
+                                              nullptr)));
+  RETURN_IF_ERROR(FromAbi(cuking_stream_synchronize(buf.ctx, nullptr)));
+  // Free device memory before post-processing (cuking.cu:757-758).
+  cuking_device_free(buf.ctx, buf.d_bits);
+  buf.d_bits = nullptr;
+  cuking_sort_results(results.data(), results.size());  // :761-765
+
+  RETURN_IF_ERROR(MakeDirs(output_dir));
+  std::ostringstream name;  // :868-870
+  name << output_dir << "/part-" << std::setw(5) << std::setfill('0') << flags.shard_index
+       << ".snappy.parquet";
+  uint64_t bytes_written = 0;
+  {
+    const std::string err = cuking_host::WriteResults(
+        name.str(), results.data(), results.size(), metadata.samples, &bytes_written);
+    if (!err.empty()) return Unknown(err);
+  }
+  Done(&sw);
+  std::cout << "Wrote " << CeilMiB(bytes_written) << " MiB." << std::endl;
+
+  // Machine-readable summary (extends the reference's phase log).
+  const uint64_t pairs = cuking_submatrix_num_pairs(&sm);
+  const double rate = kernel_seconds > 0 ? pairs / kernel_seconds : 0;
+  std::cout << "{\"pairs\": " << pairs << ", \"triples\": " << num_triples.load()
+            << ", \"results\": " << num_results << ", \"kernel_seconds\": "
+            << std::setprecision(6) << kernel_seconds << ", \"pairs_per_second\": "
+            << std::setprecision(1) << rate << ", \"algorithmic_GBps\": "
+            << rate * cuking_bytes_per_pair(words_per_sample) / 1e9 << "}" << std::endl;
+  return Status::Ok();
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  Flags flags;
+  const std::string parse_error = cuking_host::ParseFlags(argc, argv, &flags);
+  if (!parse_error.empty()) {
+    std::cerr << "ERROR: " << parse_error << std::endl;
+    return 1;
+  }
+  if (flags.help) {
+    std::cout << cuking_host::Usage();
+    return 0;
+  }
+  const Status status = Run(flags);
+  if (!status.ok()) {  // cuking.cu:889-892
+    std::cerr << std::endl
+              << "Error: " << status.code << ": " << status.message << std::endl;
+    return 1;
+  }
+  return 0;
+}

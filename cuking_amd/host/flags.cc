@@ -1,0 +1,147 @@
+#include "flags.h"
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdlib>
+#include <cstring>
+
+namespace cuking_host {
+
+namespace {
+
+std::string Normalise(std::string name) {
+  std::replace(name.begin(), name.end(), '-', '_');
+  return name;
+}
+
+bool ParseUnsigned(const std::string &text, uint64_t max, uint64_t *out) {
+  if (text.empty() || text[0] == '-' || text[0] == '+') return false;
+  errno = 0;
+  char *end = nullptr;
+  const unsigned long long v = strtoull(text.c_str(), &end, 10);
+  if (errno != 0 || end == text.c_str() || *end != '\0' || v > max) return false;
+  *out = v;
+  return true;
+}
+
+bool ParseFloat(const std::string &text, float *out) {
+  if (text.empty()) return false;
+  errno = 0;
+  char *end = nullptr;
+  const float v = strtof(text.c_str(), &end);
+  if (end == text.c_str() || *end != '\0') return false;
+  *out = v;
+  return true;
+}
+
+}  // namespace
+
+std::string Usage() {
+  return "cuking (MI355X) -- KING-robust kinship for all sample pairs\n"
+         "  --input_uri=DIR        directory with metadata.json + *.parquet "
+         "(row_idx, col_idx, n_alt_alleles)\n"
+         "  --output_uri=DIR       receives part-<shard>.snappy.parquet\n"
+         "  --kin_threshold=F      only store kin > F (default 0.0884)\n"
+         "  --split_factor=K       split the relatedness matrix into K(K+1)/2 "
+         "shards (default 1)\n"
+         "  --shard_index=I        which shard to compute (default 0)\n"
+         "  --max_results=N        result records to reserve (default 10485760)\n"
+         "  --num_reader_threads=N Parquet reader threads (default 36)\n"
+         "  --requester_pays_project=P  accepted for compatibility, unused\n"
+         "  --device=D             GPU index (default 0)\n"
+         "  --kernel=tiled|stream  device kernel (default tiled)\n"
+         "  --pack=host|device     where triples are packed (default host)\n"
+         "  --dump_bitset=FILE     diagnostic: write the packed bitset (raw "
+         "little-endian u64) and exit before any GPU work\n"
+         "Dashes and underscores are interchangeable in flag names.\n";
+}
+
+std::string ParseFlags(int argc, char **argv, Flags *flags) {
+  for (int a = 1; a < argc; ++a) {
+    std::string arg = argv[a];
+    if (arg == "--help" || arg == "-h" || arg == "-help") {
+      flags->help = true;
+      continue;
+    }
+    if (arg.size() < 3 || arg[0] != '-') return "Unexpected argument: " + arg;
+    // Abseil accepts -flag and --flag.
+    arg = arg.substr(arg[1] == '-' ? 2 : 1);
+    std::string name, value;
+    bool has_value = false;
+    const size_t eq = arg.find('=');
+    if (eq != std::string::npos) {
+      name = arg.substr(0, eq);
+      value = arg.substr(eq + 1);
+      has_value = true;
+    } else {
+      name = arg;
+    }
+    name = Normalise(name);
+    auto need_value = [&]() -> bool {
+      if (has_value) return true;
+      if (a + 1 >= argc) return false;
+      value = argv[++a];
+      return true;
+    };
+    uint64_t u = 0;
+    if (name == "input_uri") {
+      if (!need_value()) return "Missing value for --input_uri";
+      flags->input_uri = value;
+    } else if (name == "output_uri") {
+      if (!need_value()) return "Missing value for --output_uri";
+      flags->output_uri = value;
+    } else if (name == "requester_pays_project") {
+      if (!need_value()) return "Missing value for --requester_pays_project";
+      flags->requester_pays_project = value;
+    } else if (name == "num_reader_threads") {
+      if (!need_value() || !ParseUnsigned(value, SIZE_MAX, &u))
+        return "Illegal value '" + value + "' specified for flag 'num_reader_threads'";
+      flags->num_reader_threads = (size_t)u;
+    } else if (name == "max_results") {
+      if (!need_value() || !ParseUnsigned(value, UINT32_MAX, &u))
+        return "Illegal value '" + value + "' specified for flag 'max_results'";
+      flags->max_results = (uint32_t)u;
+    } else if (name == "kin_threshold") {
+      if (!need_value() || !ParseFloat(value, &flags->kin_threshold))
+        return "Illegal value '" + value + "' specified for flag 'kin_threshold'";
+    } else if (name == "split_factor") {
+      if (!need_value() || !ParseUnsigned(value, UINT32_MAX, &u))
+        return "Illegal value '" + value + "' specified for flag 'split_factor'";
+      flags->split_factor = (uint32_t)u;
+    } else if (name == "shard_index") {
+      if (!need_value() || !ParseUnsigned(value, UINT32_MAX, &u))
+        return "Illegal value '" + value + "' specified for flag 'shard_index'";
+      flags->shard_index = (uint32_t)u;
+    } else if (name == "device") {
+      if (!need_value() || !ParseUnsigned(value, 1023, &u))
+        return "Illegal value '" + value + "' specified for flag 'device'";
+      flags->device = (int)u;
+    } else if (name == "kernel") {
+      if (!need_value() || (value != "tiled" && value != "stream"))
+        return "Illegal value '" + value + "' specified for flag 'kernel'";
+      flags->kernel = value;
+    } else if (name == "dump_bitset") {
+      if (!need_value()) return "Missing value for --dump_bitset";
+      flags->dump_bitset = value;
+    } else if (name == "pack") {
+      if (!need_value() || (value != "host" && value != "device"))
+        return "Illegal value '" + value + "' specified for flag 'pack'";
+      flags->pack = value;
+    } else {
+      return "Unknown command line flag '" + name + "'";
+    }
+  }
+  return "";
+}
+
+std::string ValidateFlags(const Flags &f) {
+  if (f.input_uri.empty()) return "No input URI specified";          // :438-440
+  if (f.output_uri.empty()) return "No output URI specified";        // :444-446
+  if (f.num_reader_threads == 0) return "Invalid number of reader threads";  // :450-452
+  if (f.split_factor == 0) return "Invalid split factor";            // :455-457
+  const uint64_t shards = (uint64_t)f.split_factor * ((uint64_t)f.split_factor + 1) / 2;
+  if (f.shard_index >= shards) return "Invalid shard index";         // :460-462
+  return "";
+}
+
+}  // namespace cuking_host

@@ -1,0 +1,41 @@
+// Command-line flags of the `cuking` binary: same names, defaults and
+// validation as the reference's Abseil flags (cuking.cu:27-52, :436-465),
+// without Abseil.  Both spellings are accepted: the binary's own
+// `--kin_threshold` and the wrapper's `--kin-threshold`
+// (cloud_batch_submit.py:28-32), as `--flag=value` or `--flag value`.
+#ifndef CUKING_AMD_HOST_FLAGS_H_
+#define CUKING_AMD_HOST_FLAGS_H_
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+namespace cuking_host {
+
+struct Flags {
+  std::string input_uri;                // cuking.cu:27
+  std::string output_uri;               // :30
+  std::string requester_pays_project;   // :33 (accepted, unused: no GCS here)
+  size_t num_reader_threads = 36;       // :36
+  uint32_t max_results = 10u << 20;     // :40
+  float kin_threshold = 0.0884f;        // :43
+  uint32_t split_factor = 1;            // :46
+  uint32_t shard_index = 0;             // :49
+  // Additions (no reference counterpart).
+  int device = 0;                       // HIP device index
+  std::string kernel = "tiled";         // tiled | stream
+  std::string pack = "host";            // host | device
+  std::string dump_bitset;              // diagnostic: write the packed host
+                                        // bitset here and exit (no GPU used)
+  bool help = false;
+};
+
+// Returns "" on success, otherwise the error message.
+std::string ParseFlags(int argc, char **argv, Flags *flags);
+// The reference's validation order and messages (cuking.cu:437-462).
+std::string ValidateFlags(const Flags &flags);
+std::string Usage();
+
+}  // namespace cuking_host
+
+#endif  // CUKING_AMD_HOST_FLAGS_H_

@@ -1,0 +1,35 @@
+// Parquet boundary of the `cuking` binary, on Arrow/Parquet C++ (the reference
+// links Arrow 8.0.0, Dockerfile:116; here the copy bundled with pyarrow).
+//   input : cuking.cu:574-672 -- three columns BY POSITION, INT64 / INT64 /
+//           INT32 (row_idx, col_idx, n_alt_alleles), all row groups.
+//   output: cuking.cu:767-863 -- i, j (String), kin (FLOAT), ibs0/1/2 (INT32),
+//           all REQUIRED, SNAPPY, one row group.
+#ifndef CUKING_AMD_HOST_PARQUET_IO_H_
+#define CUKING_AMD_HOST_PARQUET_IO_H_
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "cuking_amd.h"
+
+namespace cuking_host {
+
+struct Triples {
+  std::vector<int64_t> row_idx, col_idx;
+  std::vector<int32_t> n_alt_alleles;
+};
+
+// Reads one input table.  Spark writes OPTIONAL columns: those are accepted;
+// a null row_idx / col_idx is an error, a null n_alt_alleles drops the entry
+// (= missing genotype).  Returns "" or the error message.
+std::string ReadTriples(const std::string &path, Triples *out);
+
+// Writes `results[0..n)` (already sorted) with sample ids looked up by index.
+std::string WriteResults(const std::string &path, const cuking_result *results,
+                         size_t n, const std::vector<std::string> &sample_ids,
+                         uint64_t *bytes_written);
+
+}  // namespace cuking_host
+
+#endif  // CUKING_AMD_HOST_PARQUET_IO_H_

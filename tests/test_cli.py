@@ -1,0 +1,267 @@
+"""The `cuking` binary (C++ host): flags, metadata, Parquet decode + pack on CPU;
+the full Parquet-in -> kernel -> Parquet-out path on the GPU (BASELINE.json
+configs[0]: 1k samples x 10k sites through real Parquet files)."""
+import json
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import cuking_amd
+from cuking_amd import build as cbuild
+from cuking_amd.inputs import read_results, write_input_tables
+from conftest import random_genotypes
+
+CLI = cbuild.CLI_PATH
+
+
+def run_cli(*args, check=False):
+    p = subprocess.run([str(CLI), *map(str, args)], capture_output=True, text=True,
+                       timeout=600)
+    if check and p.returncode != 0:
+        raise AssertionError(f"cuking failed ({p.returncode}):\n{p.stdout}\n{p.stderr}")
+    return p
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built_cli():
+    cbuild.build_library()
+    cbuild.build_cli()
+    assert CLI.exists()
+
+
+# ---------------------------------------------------------------- flags ----
+def test_flag_validation_messages(tmp_path):
+    """cuking.cu:437-462 (messages) and :889-892 (stderr + exit code 1)."""
+    cases = [
+        ([], "No input URI specified"),
+        (["--input_uri", tmp_path], "No output URI specified"),
+        (["--input_uri", tmp_path, "--output_uri", tmp_path, "--num_reader_threads=0"],
+         "Invalid number of reader threads"),
+        (["--input_uri", tmp_path, "--output_uri", tmp_path, "--split_factor=0"],
+         "Invalid split factor"),
+        (["--input-uri", tmp_path, "--output-uri", tmp_path, "--split-factor=4",
+          "--shard-index=10"], "Invalid shard index"),
+        (["--input_uri=gs://bucket/in", "--output_uri", tmp_path], "Unsupported URI"),
+    ]
+    for args, msg in cases:
+        p = run_cli(*args)
+        assert p.returncode == 1, args
+        assert "Error: INVALID_ARGUMENT: " in p.stderr and msg in p.stderr, p.stderr
+    p = run_cli("--no_such_flag=1")
+    assert p.returncode == 1 and "Unknown command line flag" in p.stderr
+    p = run_cli("--kin_threshold=abc")
+    assert p.returncode == 1 and "Illegal value" in p.stderr
+    assert run_cli("--help").returncode == 0
+
+
+def test_missing_inputs(tmp_path):
+    out = tmp_path / "out"
+    p = run_cli("--input_uri", tmp_path / "nope", "--output_uri", out,
+                "--dump_bitset", tmp_path / "b.bin")
+    assert p.returncode == 1 and "Failed to read metadata" in p.stderr
+    empty = tmp_path / "empty"
+    empty.mkdir()
+    (empty / "metadata.json").write_text('{"num_sites": 3, "samples": ["a"]}')
+    p = run_cli("--input_uri", empty, "--output_uri", out, "--dump_bitset", tmp_path / "b.bin")
+    assert p.returncode == 1 and "No input files found" in p.stderr  # :542-544
+    (empty / "metadata.json").write_text('{"num_sites": 3, "samples": ["a"')
+    p = run_cli("--input_uri", empty, "--output_uri", out, "--dump_bitset", tmp_path / "b.bin")
+    assert p.returncode == 1 and "Failed to parse metadata JSON" in p.stderr  # :485-487
+
+
+# ------------------------------------------------- decode + pack (CPU) ----
+def dump_bits(in_dir, tmp_path, n_stored, wps, *extra):
+    dump = tmp_path / "bits.bin"
+    run_cli("--input_uri", in_dir, "--output_uri", tmp_path / "unused",
+            "--dump_bitset", dump, "--num_reader_threads=4", *extra, check=True)
+    return np.fromfile(dump, dtype=np.uint64).reshape(n_stored, wps)
+
+
+@pytest.mark.parametrize("layout", [
+    dict(compression="zstd", nullable=True, spark_layout=True),      # Spark / Hail
+    dict(compression="snappy", nullable=False, spark_layout=False),
+    dict(compression=None, nullable=True, spark_layout=False, use_dictionary=False),
+    dict(compression="zstd", nullable=False, spark_layout=True, row_group_size=1000,
+         shuffle_seed=3),
+    dict(compression="gzip", nullable=True, spark_layout=False, row_group_size=777),
+])
+def test_parquet_decode_and_pack_match_oracle(tmp_path, oracle, layout):
+    rng = np.random.default_rng(17)
+    n, m = 37, 523
+    geno = random_genotypes(rng, n, m, missing=0.15)
+    ids = [f"sample \"{k}\" é中" if k % 5 == 0 else f"NA{k:05d}" for k in range(n)]
+    in_dir = tmp_path / "in"
+    write_input_tables(in_dir, geno, ids, num_files=5, **layout)
+    wps = cuking_amd.words_per_sample(m)
+    got = dump_bits(in_dir, tmp_path, n, wps)
+    assert np.array_equal(got, oracle.bitset_from_genotypes(geno))
+    # a shard only keeps its own samples, in Submatrix storage order
+    for k, shard in ((2, 1), (3, 4)):
+        osm = oracle.submatrix(n, k, shard)
+        got = dump_bits(in_dir, tmp_path, osm.i_end - osm.i_begin +
+                        (0 if osm.i_begin == osm.j_begin else osm.j_end - osm.j_begin),
+                        wps, f"--split_factor={k}", f"--shard_index={shard}")
+        assert np.array_equal(got, oracle.bitset_from_genotypes(geno, osm))
+
+
+def test_null_genotypes_are_missing_and_bad_inputs_fail(tmp_path, oracle):
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    d = tmp_path / "in"
+    d.mkdir()
+    (d / "metadata.json").write_text(json.dumps({"num_sites": 40, "samples": ["a", "b"]}))
+    tbl = pa.table({"row_idx": pa.array([0, 1, 2, 3], pa.int64()),
+                    "col_idx": pa.array([0, 0, 1, 1], pa.int64()),
+                    "n_alt_alleles": pa.array([1, None, 2, 0], pa.int32())})
+    pq.write_table(tbl, d / "t.parquet")
+    got = dump_bits(d, tmp_path, 2, 2)
+    geno = np.full((2, 40), -1, dtype=np.int8)
+    geno[0, 0], geno[1, 2], geno[1, 3] = 1, 2, 0
+    assert np.array_equal(got, oracle.bitset_from_genotypes(geno))
+
+    def expect_fail(table, needle):
+        for f in d.glob("*.parquet"):
+            f.unlink()
+        pq.write_table(table, d / "t.parquet")
+        p = run_cli("--input_uri", d, "--output_uri", tmp_path / "o", "--dump_bitset",
+                    tmp_path / "x.bin")
+        assert p.returncode == 1 and needle in p.stderr, p.stderr
+
+    expect_fail(pa.table({"row_idx": pa.array([0], pa.int64()),
+                          "col_idx": pa.array([0], pa.int64()),
+                          "n_alt_alleles": pa.array([3], pa.int32())}),
+                "Invalid value for n_alt_alleles (3)")          # cuking.cu:698-702
+    expect_fail(pa.table({"row_idx": pa.array([0], pa.int64()),
+                          "col_idx": pa.array([0], pa.int64())}),
+                "Expected 3 columns, found 2")                  # :586-590
+    expect_fail(pa.table({"row_idx": pa.array([0], pa.int32()),
+                          "col_idx": pa.array([0], pa.int64()),
+                          "n_alt_alleles": pa.array([1], pa.int32())}),
+                "Expected INT64 type, found INT32")             # :608-613
+    expect_fail(pa.table({"row_idx": pa.array([64], pa.int64()),
+                          "col_idx": pa.array([0], pa.int64()),
+                          "n_alt_alleles": pa.array([1], pa.int32())}),
+                "outside the 64 padded sites")
+    expect_fail(pa.table({"row_idx": pa.array([None], pa.int64()),
+                          "col_idx": pa.array([0], pa.int64()),
+                          "n_alt_alleles": pa.array([1], pa.int32())}),
+                "null values are not allowed")
+
+
+def test_without_gpu_the_cli_fails_loudly(tmp_path):
+    if cuking_amd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    geno = random_genotypes(np.random.default_rng(0), 4, 40)
+    write_input_tables(tmp_path / "in", geno, num_files=1)
+    p = run_cli("--input_uri", tmp_path / "in", "--output_uri", tmp_path / "out")
+    assert p.returncode == 1 and "no CPU path" in p.stderr
+    assert not (tmp_path / "out").exists()
+
+
+# ----------------------------------------------------- end to end (GPU) ----
+def c0_genotypes():
+    rng = np.random.default_rng(20240229)
+    n, m = 1000, 10000
+    geno = random_genotypes(rng, n, m, missing=0.01)
+    geno[900] = geno[10]                          # duplicate
+    for child, (a, b) in {901: (20, 21), 902: (20, 21), 903: (22, 23)}.items():
+        for s in range(m):                         # crude Mendelian children
+            ga, gb = geno[a, s], geno[b, s]
+            if ga < 0 or gb < 0:
+                geno[child, s] = -1
+                continue
+            ta = ga // 2 if ga != 1 else rng.integers(0, 2)
+            tb = gb // 2 if gb != 1 else rng.integers(0, 2)
+            geno[child, s] = ta + tb
+    return geno
+
+
+@pytest.fixture(scope="module")
+def c0(tmp_path_factory):
+    d = tmp_path_factory.mktemp("c0")
+    geno = c0_genotypes()
+    ids = [f"HG{k:05d}" for k in range(geno.shape[0])]
+    write_input_tables(d / "in", geno, ids, num_files=8, compression="zstd",
+                       nullable=True, spark_layout=True)
+    return dict(dir=d, geno=geno, ids=ids)
+
+
+def expected_table(oracle, geno, ids, thr, k=1, shard=0):
+    osm = oracle.submatrix(geno.shape[0], k, shard)
+    res, ovf, _ = oracle.compute(osm, oracle.bitset_from_genotypes(geno, osm), thr)
+    assert ovf == 0
+    return res
+
+
+def check_output(path, exp, ids):
+    import pyarrow.parquet as pq
+    meta = pq.ParquetFile(path).metadata
+    assert meta.num_row_groups == 1                                # cuking.cu:804
+    schema = pq.ParquetFile(path).schema
+    names = [schema.column(k).name for k in range(6)]
+    assert names == ["i", "j", "kin", "ibs0", "ibs1", "ibs2"]      # :770-788
+    phys = [schema.column(k).physical_type for k in range(6)]
+    assert phys == ["BYTE_ARRAY", "BYTE_ARRAY", "FLOAT", "INT32", "INT32", "INT32"]
+    assert all(schema.column(k).max_definition_level == 0 for k in range(6))  # REQUIRED
+    assert str(schema.column(0).logical_type) == "String"
+    assert all(meta.row_group(0).column(k).compression == "SNAPPY" for k in range(6))
+    t = pq.read_table(path)
+    assert t.num_rows == len(exp)
+    assert t.column("i").to_pylist() == [ids[x] for x in exp["sample_i"]]
+    assert t.column("j").to_pylist() == [ids[x] for x in exp["sample_j"]]
+    kin = t.column("kin").to_numpy()
+    assert kin.dtype == np.float32
+    assert np.array_equal(kin.view(np.uint32), exp["kin"].view(np.uint32))   # bit-exact
+    for name in ("ibs0", "ibs1", "ibs2"):
+        assert np.array_equal(t.column(name).to_numpy().astype(np.uint32), exp[name])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--kernel=stream"], ["--pack=device"]])
+def test_c0_end_to_end(c0, oracle, extra):
+    """1k x 10k through real Parquet (zstd, OPTIONAL, Spark layout incl. the
+    _temporary junk) -> bit-exact records vs the CPU path."""
+    out = c0["dir"] / ("out_" + "_".join(a.strip("-").replace("=", "_") for a in extra))
+    p = run_cli("--input-uri", c0["dir"] / "in", "--output-uri", out,
+                "--kin-threshold=0.05", "--num_reader_threads=8", *extra, check=True)
+    assert "Found 8 input files." in p.stdout
+    exp = expected_table(oracle, c0["geno"], c0["ids"], 0.05)
+    assert len(exp) >= 5
+    files = sorted(f.name for f in out.iterdir())
+    assert files == ["part-00000.snappy.parquet"]                   # :868-870
+    check_output(out / files[0], exp, c0["ids"])
+    summary = json.loads(p.stdout.strip().splitlines()[-1])
+    assert summary["pairs"] == 1000 * 999 // 2 and summary["results"] == len(exp)
+
+
+@pytest.mark.gpu
+def test_c0_split_factor_shards(c0, oracle):
+    """README.md:94-102: k = 3 => 6 shards, each its own part file."""
+    out = c0["dir"] / "out_split"
+    thr = 0.0884
+    parts = []
+    for shard in range(6):
+        run_cli("--input_uri", c0["dir"] / "in", "--output_uri", f"file://{out}",
+                "--split_factor=3", f"--shard_index={shard}", check=True)
+        exp = expected_table(oracle, c0["geno"], c0["ids"], thr, 3, shard)
+        check_output(out / f"part-{shard:05d}.snappy.parquet", exp, c0["ids"])
+        parts.append(exp)
+    whole = expected_table(oracle, c0["geno"], c0["ids"], thr)
+    assert sum(len(p) for p in parts) == len(whole)
+    t = read_results(out)
+    assert t.num_rows == len(whole)
+    got = sorted(zip(t.column("i").to_pylist(), t.column("j").to_pylist()))
+    assert got == sorted((c0["ids"][a], c0["ids"][b])
+                         for a, b in zip(whole["sample_i"], whole["sample_j"]))
+
+
+@pytest.mark.gpu
+def test_cli_result_overflow(c0):
+    p = run_cli("--input_uri", c0["dir"] / "in", "--output_uri", c0["dir"] / "out_ovf",
+                "--kin_threshold=-10", "--max_results=1000")
+    assert p.returncode == 1
+    assert ("Error: RESOURCE_EXHAUSTED: Could not store all results: try increasing "
+            "the --max_results parameter.") in p.stderr              # :747-751
+    assert not (c0["dir"] / "out_ovf" / "part-00000.snappy.parquet").exists()
