@@ -59,6 +59,10 @@ def parse_args():
                     help="target CPU-baseline time (0 disables it)")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="OpenMP threads of the CPU baseline (0 = min(16, available))")
+    ap.add_argument("--dist-mode", default="staged", choices=["staged", "simple"],
+                    help="N>1: overlap the chunked bitset broadcast with compute "
+                         "(staged) or broadcast first (simple)")
+    ap.add_argument("--chunks", type=int, default=8, help="broadcast chunks (staged)")
     ap.add_argument("--seed", type=int, default=20240229)
     return ap.parse_args()
 
@@ -127,7 +131,9 @@ def main():
     import torch
     import torch.distributed as dist
     import cuking_amd
-    from cuking_amd.dist import all_pairs_king, tile_partition
+    from cuking_amd.dist import (GpuStagedOps, all_pairs_king,
+                                 all_pairs_king_staged, row_partition,
+                                 tile_partition)
     from cuking_amd.synth import cohort_to_device, plan_cohort
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -136,11 +142,20 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch with "
                          "torch.distributed.run --nproc-per-node N")
+    # Rehearsal on a one-GPU box: CUKING_BENCH_REHEARSAL=1 puts every rank on
+    # cuda:0 and uses gloo for the collectives (RCCL refuses two ranks on one
+    # device).  Never the measured configuration.
+    rehearsal = os.environ.get("CUKING_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
 
     n = args.samples or int(round(10000 * math.sqrt(world)))
     m = args.sites
@@ -179,12 +194,19 @@ def main():
         return results, count, ovf
 
     gathered = [None]
+    staged = world > 1 and args.dist_mode == "staged" and args.kernel == "tiled"
+    tile = ctx.tile_samples()
+    staged_ops = (GpuStagedOps(ctx, sm, wps, bits, thr, args.max_results)
+                  if staged else None)
 
     def step():
         if world == 1:
             index_flag.zero_()
             ctx.compute_king(sm, wps, bits, thr, args.max_results, results,
                              index_flag[0:1], index_flag[1:2])
+        elif staged:
+            gathered[0], _ = all_pairs_king_staged(staged_ops, n, tile, bits,
+                                                   num_chunks=args.chunks)
         else:
             gathered[0], _ = all_pairs_king(compute_tiles, num_tiles, bits)
 
@@ -232,8 +254,20 @@ def main():
         bpp = cuking_amd.bytes_per_pair(wps)
         # Dominant kernel = the pair kernel; rank 0's launches cover its own
         # share of the pairs.
-        launch_pairs = pairs if world == 1 else pairs * (my_tiles[1] - my_tiles[0]) / max(num_tiles, 1)
-        king_ms = timing.king_ms / max(timing.king_launches, 1)
+        if world == 1:
+            launch_pairs, launches = pairs, timing.king_launches
+        else:
+            # rank 0's share of the pairs per step; its kernel time per step is
+            # the sum over its launches (rectangles on two streams may overlap,
+            # so this is an upper bound on the time the pair kernel was busy)
+            if staged:
+                t_rows = (n + tile - 1) // tile
+                a, b = row_partition(t_rows, world)[0]
+                share = sum(t_rows - r for r in range(a, b)) / (t_rows * (t_rows + 1) / 2)
+            else:
+                share = (my_tiles[1] - my_tiles[0]) / max(num_tiles, 1)
+            launch_pairs, launches = pairs * share, args.steps
+        king_ms = timing.king_ms / max(launches, 1)
         achieved = launch_pairs * bpp / (king_ms * 1e-3) / 1e9 if king_ms > 0 else 0.0
         workload = f"{n} samples x {m} sites, kin-threshold {thr}"
         key = f"{n}x{m}"
@@ -269,7 +303,8 @@ def main():
                        "pairs": pairs, "kin_threshold": thr,
                        "results_per_step": int(len(recs)),
                        "kernel": args.kernel,
-                       "parallelism": f"pair-space tiles over {world} GPU(s)"},
+                       "parallelism": f"pair-space tiles over {world} GPU(s)"
+                                      + (f", {args.dist_mode} bitset broadcast" if world > 1 else "")},
             "roofline": roofline,
         }
         if world == 1 and args.cpu_seconds > 0:

@@ -204,6 +204,30 @@ class KingContext:
             check(self.lib.cuking_compute_king_tiles(
                 *args, tile_range[0], tile_range[1], *tail))
 
+    def prepare_samples(self, submatrix: Submatrix, words_per_sample: int,
+                        bit_sets, sample_begin: int, sample_end: int,
+                        stream=None) -> None:
+        """Staged operator, step 1 (diagonal block): convert samples
+        [sample_begin, sample_end) into the kernel layout."""
+        self._check_bits(submatrix, words_per_sample, bit_sets)
+        check(self.lib.cuking_prepare_samples(
+            self.handle, C.byref(submatrix.c), words_per_sample,
+            bit_sets.data_ptr(), sample_begin, sample_end,
+            _stream_handle(stream)))
+
+    def compute_king_rect(self, submatrix: Submatrix, words_per_sample: int,
+                          rows, cols, kin_threshold: float, max_results: int,
+                          results, result_index, result_overflow,
+                          stream=None) -> None:
+        """Staged operator, step 2: pairs (i < j) of rows x cols (sample index
+        ranges) from the prepared layout; appends like compute_king."""
+        assert results.numel() * results.element_size() >= max_results * 24
+        check(self.lib.cuking_compute_king_rect(
+            self.handle, C.byref(submatrix.c), words_per_sample, rows[0],
+            rows[1], cols[0], cols[1], kin_threshold, max_results,
+            results.data_ptr(), result_index.data_ptr(),
+            result_overflow.data_ptr(), _stream_handle(stream)))
+
     def compute_counts(self, submatrix: Submatrix, words_per_sample: int,
                        bit_sets, stream=None) -> np.ndarray:
         """Diagnostic: the six sums (cuking.cu:232-239) of every pair, as a

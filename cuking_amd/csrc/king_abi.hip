@@ -179,7 +179,8 @@ cuking_status check_block(const cuking_submatrix *sm,
 cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
                       uint32_t words_per_sample, const uint64_t *d_bit_sets,
                       hipStream_t stream, PlaneGeometry *geo_out,
-                      TileSpace *tiles_out) {
+                      TileSpace *tiles_out, uint32_t s_tile_begin = 0,
+                      uint32_t s_tile_end = 0xFFFFFFFFu) {
   const TiledVariant &v = tiled_variant(ctx->variant);
   const PlaneGeometry geo = make_geometry(sm, words_per_sample, v);
   const TileSpace tiles = make_tiles(geo, v, ctx->band_rows);
@@ -224,7 +225,7 @@ cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
   EventPair *ev = nullptr;
   if (ctx->timing) HIP_TRY(ctx->prepare_timer.begin(stream, &ev));
   HIP_TRY(launch_prepare_planes(d_bit_sets, words_per_sample, geo, ctx->planes,
-                                stream));
+                                s_tile_begin, s_tile_end, stream));
   if (ev) HIP_TRY(hipEventRecord(ev->stop, stream));
   return CUKING_OK;
 }
@@ -267,6 +268,7 @@ cuking_status run_tiled(cuking_ctx *ctx, const cuking_submatrix &sm,
   a.result_index = d_result_index;
   a.result_overflow = d_result_overflow;
   a.dense_counts = d_counts;
+  a.rect_rows = a.rect_row0 = a.rect_col0 = 0;
 
   EventPair *ev = nullptr;
   if (ctx->timing) HIP_TRY(ctx->king_timer.begin(stream, &ev));
@@ -673,6 +675,100 @@ cuking_status cuking_compute_king_tiles(
   return run_tiled(ctx, *sm, words_per_sample, d_bit_sets, tile_begin, tile_end,
                    false, kin_threshold, max_results, d_results, d_result_index,
                    d_result_overflow, nullptr, (hipStream_t)stream);
+}
+
+// Offsets of a sample range inside a diagonal block, in tiles.
+static cuking_status tile_span(const cuking_submatrix &sm, uint32_t tile,
+                               uint32_t begin, uint32_t end, const char *what,
+                               uint32_t *t0, uint32_t *t1) {
+  if (begin < sm.i_begin || end > sm.i_end || begin > end)
+    return fail(CUKING_ERR_INVALID_ARGUMENT, "%s range [%u, %u) outside the block",
+                what, begin, end);
+  const uint32_t b = begin - sm.i_begin, e = end - sm.i_begin;
+  if (b % tile != 0 || (e % tile != 0 && end != sm.i_end))
+    return fail(CUKING_ERR_INVALID_ARGUMENT,
+                "%s range [%u, %u) is not aligned to the %u-sample tile edge", what,
+                begin, end, tile);
+  *t0 = b / tile;
+  *t1 = (e + tile - 1) / tile;
+  return CUKING_OK;
+}
+
+cuking_status cuking_prepare_samples(cuking_ctx *ctx, const cuking_submatrix *sm,
+                                     uint32_t words_per_sample,
+                                     const uint64_t *d_bit_sets,
+                                     uint32_t sample_begin, uint32_t sample_end,
+                                     void *stream) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  st = check_compute_args(sm, words_per_sample, d_bit_sets);
+  if (st != CUKING_OK) return st;
+  if (!sm_is_diag(*sm))
+    return fail(CUKING_ERR_INVALID_ARGUMENT,
+                "staged preparation needs a diagonal block (rows == columns)");
+  const uint32_t tile = tiled_variant(ctx->variant).tile;
+  uint32_t t0, t1;
+  st = tile_span(*sm, tile, sample_begin, sample_end, "sample", &t0, &t1);
+  if (st != CUKING_OK) return st;
+  if (t0 == t1) return CUKING_OK;
+  PlaneGeometry geo;
+  TileSpace tiles;
+  // prepare() works in units of 64 plane samples.
+  return prepare(ctx, *sm, words_per_sample, d_bit_sets, (hipStream_t)stream, &geo,
+                 &tiles, t0 * (tile / 64), t1 * (tile / 64));
+}
+
+cuking_status cuking_compute_king_rect(
+    cuking_ctx *ctx, const cuking_submatrix *sm, uint32_t words_per_sample,
+    uint32_t row_begin, uint32_t row_end, uint32_t col_begin, uint32_t col_end,
+    float kin_threshold, uint32_t max_results, cuking_result *d_results,
+    uint32_t *d_result_index, uint32_t *d_result_overflow, void *stream) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  st = check_block(sm, words_per_sample);
+  if (st != CUKING_OK) return st;
+  if (!sm_is_diag(*sm))
+    return fail(CUKING_ERR_INVALID_ARGUMENT,
+                "rectangle launches need a diagonal block (rows == columns)");
+  if (!d_result_index || !d_result_overflow || (max_results && !d_results))
+    return fail(CUKING_ERR_INVALID_ARGUMENT, "null result pointer");
+  const TiledVariant &v = tiled_variant(ctx->variant);
+  const PlaneGeometry geo = make_geometry(*sm, words_per_sample, v);
+  const TileSpace tiles = make_tiles(geo, v, ctx->band_rows);
+  const size_t need = (size_t)geo.k_words * geo.s_stride * sizeof(uint4);
+  if (ctx->planes == nullptr || ctx->planes_bytes < need)
+    return fail(CUKING_ERR_FAILED_PRECONDITION,
+                "cuking_prepare_samples() has not been called for this block");
+  uint32_t r0, r1, c0, c1;
+  st = tile_span(*sm, v.tile, row_begin, row_end, "row", &r0, &r1);
+  if (st != CUKING_OK) return st;
+  st = tile_span(*sm, v.tile, col_begin, col_end, "column", &c0, &c1);
+  if (st != CUKING_OK) return st;
+  if (r0 == r1 || c0 == c1) return CUKING_OK;
+
+  TiledArgs a;
+  a.planes = ctx->planes;
+  a.geo = geo;
+  a.tiles = tiles;
+  a.band_prefix = ctx->band_prefix;  // unused in rectangle mode
+  a.tile_begin = 0;
+  a.rect_rows = r1 - r0;
+  a.rect_row0 = r0;
+  a.rect_col0 = c0;
+  a.i_begin = sm->i_begin;
+  a.j_begin = sm->j_begin;
+  a.kin_threshold = kin_threshold;
+  a.max_results = max_results;
+  a.results = d_results;
+  a.result_index = d_result_index;
+  a.result_overflow = d_result_overflow;
+  a.dense_counts = nullptr;
+  EventPair *ev = nullptr;
+  if (ctx->timing) HIP_TRY(ctx->king_timer.begin((hipStream_t)stream, &ev));
+  HIP_TRY(launch_tiled(ctx->variant, a, (uint64_t)(r1 - r0) * (c1 - c0),
+                       (hipStream_t)stream));
+  if (ev) HIP_TRY(hipEventRecord(ev->stop, (hipStream_t)stream));
+  return CUKING_OK;
 }
 
 cuking_status cuking_compute_counts(cuking_ctx *ctx, const cuking_submatrix *sm,

@@ -89,6 +89,12 @@ struct TiledArgs {
   TileSpace tiles;
   const uint64_t *band_prefix;  // device; num_bands + 1 entries
   uint64_t tile_begin;          // first tile of this launch
+  // Rectangle mode (rect_rows != 0): the launch covers tile rows
+  // [rect_row0, rect_row0 + rect_rows) x tile columns [rect_col0, ...),
+  // column-major; launch index t -> (rect_row0 + t % rect_rows,
+  // rect_col0 + t / rect_rows).  Used to start on the columns whose samples
+  // have already arrived while the rest of the bitset is still in flight.
+  uint32_t rect_rows, rect_row0, rect_col0;
   uint32_t i_begin, j_begin;    // global sample index of row / column 0
   float kin_threshold;
   uint32_t max_results;
@@ -113,9 +119,12 @@ const TiledVariant &tiled_variant(int v);
 hipError_t launch_tiled(int variant, const TiledArgs &args, uint64_t num_tiles,
                         hipStream_t stream);
 
+// Converts plane-sample tiles [s_tile_begin, s_tile_end) (units of 64 plane
+// samples) of the block.
 hipError_t launch_prepare_planes(const uint64_t *d_bit_sets,
                                  uint32_t words_per_sample,
                                  const PlaneGeometry &geo, uint4 *d_planes,
+                                 uint32_t s_tile_begin, uint32_t s_tile_end,
                                  hipStream_t stream);
 
 hipError_t launch_stream(const cuking_submatrix &sm, uint32_t words_per_sample,

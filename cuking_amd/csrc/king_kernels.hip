@@ -69,12 +69,12 @@ constexpr int kPrepWords = 16;
 
 __global__ __launch_bounds__(256) void prepare_planes_kernel(
     const uint64_t *__restrict__ bits, uint32_t words_per_sample,
-    PlaneGeometry geo, uint4 *__restrict__ planes) {
+    PlaneGeometry geo, uint4 *__restrict__ planes, uint32_t s_tile_begin) {
   __shared__ uint64_t het_lds[kPrepSamples][kPrepWords + 1];
   __shared__ uint64_t hom_lds[kPrepSamples][kPrepWords + 1];
 
   const uint32_t plane_words = words_per_sample / 2;
-  const uint32_t s0 = blockIdx.x * kPrepSamples;
+  const uint32_t s0 = (s_tile_begin + blockIdx.x) * kPrepSamples;
   const uint32_t w0 = blockIdx.y * kPrepWords;
 
 #pragma unroll
@@ -157,13 +157,21 @@ __global__ __launch_bounds__(TIT *TJT, MINW) void king_tiled_kernel(
 
   // --- which tile (uniform across the workgroup) ---
   const uint64_t t = a.tile_begin + blockIdx.x;
-  uint32_t lo = 0, hi = a.tiles.num_bands();
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (a.band_prefix[mid] <= t) lo = mid; else hi = mid;
-  }
   uint32_t tr, tc;
-  a.tiles.decode(lo, t - a.band_prefix[lo], &tr, &tc);
+  if (a.rect_rows != 0) {
+    tr = a.rect_row0 + (uint32_t)(t % a.rect_rows);
+    tc = a.rect_col0 + (uint32_t)(t / a.rect_rows);
+    // Below the diagonal of a diagonal block: nothing to do.  The whole
+    // workgroup leaves here, before any barrier.
+    if (a.tiles.diag && tc < tr) return;
+  } else {
+    uint32_t lo = 0, hi = a.tiles.num_bands();
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (a.band_prefix[mid] <= t) lo = mid; else hi = mid;
+    }
+    a.tiles.decode(lo, t - a.band_prefix[lo], &tr, &tc);
+  }
 
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -442,12 +450,16 @@ hipError_t launch_tiled(int variant, const TiledArgs &args, uint64_t num_tiles,
 hipError_t launch_prepare_planes(const uint64_t *d_bit_sets,
                                  uint32_t words_per_sample,
                                  const PlaneGeometry &geo, uint4 *d_planes,
+                                 uint32_t s_tile_begin, uint32_t s_tile_end,
                                  hipStream_t stream) {
-  const dim3 grid((geo.s_stride + kPrepSamples - 1) / kPrepSamples,
+  const uint32_t all = (geo.s_stride + kPrepSamples - 1) / kPrepSamples;
+  if (s_tile_end > all) s_tile_end = all;
+  if (s_tile_begin >= s_tile_end) return hipSuccess;
+  const dim3 grid(s_tile_end - s_tile_begin,
                   (geo.k_words + 2 * kPrepWords - 1) / (2 * kPrepWords));
-  if (grid.x == 0 || grid.y == 0) return hipSuccess;
+  if (grid.y == 0) return hipSuccess;
   prepare_planes_kernel<<<grid, dim3(256), 0, stream>>>(
-      d_bit_sets, words_per_sample, geo, d_planes);
+      d_bit_sets, words_per_sample, geo, d_planes, s_tile_begin);
   return hipGetLastError();
 }
 

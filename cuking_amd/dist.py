@@ -15,6 +15,20 @@ exactly two exchange steps:
 
 Every tile costs the same (diagonal tiles are evaluated in full and masked at
 emit), so equal tile counts are equal work.
+
+Two forms of the sharded pass:
+
+``all_pairs_king``         broadcast everything, then each rank runs its range
+                           of the tile enumeration (simple; the broadcast is
+                           exposed).
+``all_pairs_king_staged``  the broadcast is cut into sample chunks sent in
+                           ascending order; rank r owns a band of rows (equal
+                           tile counts per band) and, as soon as chunk c has
+                           landed, converts it and launches the rectangle
+                           rows(r) x chunk c.  A pair (i < j) only needs chunk(j)
+                           and everything before it, so every rank computes
+                           while later chunks are still on the wire: the
+                           exchange hides behind the kernel.
 """
 from __future__ import annotations
 
@@ -52,8 +66,8 @@ def gather_results(local, count: int, overflow: int, dst: int = 0,
     import torch.distributed as dist
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
-    meta = torch.tensor([count, overflow], dtype=torch.int64,
-                        device=local.device)
+    meta_dev = "cpu" if dist.get_backend(group) == "gloo" else local.device
+    meta = torch.tensor([count, overflow], dtype=torch.int64, device=meta_dev)
     metas = [torch.zeros_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta, group=group)
     counts = [int(m[0]) for m in metas]
@@ -64,6 +78,8 @@ def gather_results(local, count: int, overflow: int, dst: int = 0,
     width = max(max(counts), 1)
     send = torch.zeros((width, 6), dtype=torch.int32, device=local.device)
     send[:count] = local[:count]
+    if dist.get_backend(group) == "gloo":
+        send = send.cpu()   # gloo gathers host tensors only (CPU rehearsals)
     recv = ([torch.zeros_like(send) for _ in range(world)]
             if rank == dst else None)
     dist.gather(send, recv, dst=dst, group=group)
@@ -89,3 +105,140 @@ def all_pairs_king(compute_tiles: Callable, num_tiles: int, bit_sets,
     begin, end = tile_partition(num_tiles, world)[rank]
     local, count, overflow = compute_tiles(bit_sets, begin, end)
     return gather_results(local, count, overflow, dst=dst, group=group), (begin, end)
+
+
+# ---------------------------------------------------------------------------
+# Staged (overlapped) form
+# ---------------------------------------------------------------------------
+def row_partition(num_tile_rows: int, world_size: int) -> List[Tuple[int, int]]:
+    """Bands of tile rows with (nearly) equal numbers of upper-triangle tiles:
+    tile row r holds num_tile_rows - r tiles (the diagonal tile included)."""
+    t = num_tile_rows
+    total = t * (t + 1) // 2
+    bounds, acc, row = [0], 0, 0
+    for r in range(1, world_size):
+        target = total * r // world_size
+        while row < t and acc + (t - row) <= target:
+            acc += t - row
+            row += 1
+        bounds.append(row)
+    bounds.append(t)
+    return [(bounds[k], bounds[k + 1]) for k in range(world_size)]
+
+
+def chunk_ranges(num_samples: int, tile: int, num_chunks: int) -> List[Tuple[int, int]]:
+    """Ascending, tile-aligned sample chunks covering [0, num_samples)."""
+    tiles = (num_samples + tile - 1) // tile
+    num_chunks = max(1, min(num_chunks, tiles))
+    out = []
+    for c in range(num_chunks):
+        b = tiles * c // num_chunks * tile
+        e = min(tiles * (c + 1) // num_chunks * tile, num_samples)
+        if e > b:
+            out.append((b, e))
+    return out
+
+
+def staged_schedule(num_samples: int, tile: int, world: int, rank: int,
+                    num_chunks: int):
+    """What rank ``rank`` does per broadcast chunk: ((row_begin, row_end),
+    [((chunk_begin, chunk_end), rect or None), ...]) with rect = (rows, cols)
+    sample ranges.  A pair (i < j) is evaluated with the chunk that holds j."""
+    tiles = (num_samples + tile - 1) // tile
+    tr0, tr1 = row_partition(tiles, world)[rank]
+    ra, rb = min(tr0 * tile, num_samples), min(tr1 * tile, num_samples)
+    steps = []
+    for c0, c1 in chunk_ranges(num_samples, tile, num_chunks):
+        if c1 <= ra or ra == rb:
+            steps.append(((c0, c1), None))
+        else:
+            steps.append(((c0, c1), ((ra, min(rb, c1)), (max(c0, ra), c1))))
+    return (ra, rb), steps
+
+
+def all_pairs_king_staged(ops, num_samples: int, tile: int, bit_sets,
+                          num_chunks: int = 8, src: int = 0, dst: int = 0,
+                          group=None):
+    """One sharded pass with the bitset exchange overlapped with compute.
+
+    ``bit_sets`` is the [num_samples, words_per_sample] tensor (valid on
+    ``src``, receive buffer elsewhere).  ``ops`` supplies the per-rank device
+    work (see ``GpuStagedOps``): ``begin()``, ``prepare(s0, s1)``,
+    ``compute_rect((r0, r1), (c0, c1))`` and ``finish() -> (records, count,
+    overflow)``.  Returns (sorted records on dst else None, (row_begin, row_end))."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    (ra, rb), steps = staged_schedule(num_samples, tile, world, rank, num_chunks)
+
+    ops.begin()
+    # All chunk broadcasts are enqueued up front; they complete in order.
+    works = [dist.broadcast(bit_sets[c0:c1], src=src, group=group, async_op=True)
+             for (c0, c1), _ in steps] if world > 1 else []
+    for k, ((c0, c1), rect) in enumerate(steps):
+        if world > 1 and rank != src:
+            works[k].wait()        # nccl: the current stream waits, not the host
+        if rect is None:
+            continue               # this rank never reads these samples
+        ops.prepare(c0, c1)
+        ops.compute_rect(*rect)
+    for w in works:                # the source's sends, too, before reuse
+        w.wait()
+    local, count, overflow = ops.finish()
+    if world == 1:
+        if overflow:
+            raise ResourceExhaustedError(
+                "Could not store all results: try increasing the --max_results "
+                "parameter.")
+        recs = np.ascontiguousarray(local[:count].cpu().numpy()).view(np.uint32)
+        return sort_results(recs.reshape(-1).view(KING_RESULT_DTYPE).copy()), (ra, rb)
+    return gather_results(local, count, overflow, dst=dst, group=group), (ra, rb)
+
+
+class GpuStagedOps:
+    """Device side of ``all_pairs_king_staged`` on one GPU: layout conversion on
+    the current stream, rectangle kernels alternating over side streams (so
+    the tail of one launch overlaps the head of the next), results appended
+    into one buffer."""
+
+    def __init__(self, ctx, submatrix, words_per_sample: int, bit_sets,
+                 kin_threshold: float, max_results: int, num_streams: int = 2):
+        import torch
+        self.ctx, self.sm, self.wps, self.bits = ctx, submatrix, words_per_sample, bit_sets
+        self.thr, self.max_results = kin_threshold, max_results
+        dev = bit_sets.device
+        self.results = torch.zeros((max(max_results, 1), 6), dtype=torch.int32, device=dev)
+        self.index_flag = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(num_streams)]
+        self.launches = 0
+
+    def begin(self):
+        self.index_flag.zero_()
+        self.launches = 0
+
+    def prepare(self, s0: int, s1: int):
+        self.ctx.prepare_samples(self.sm, self.wps, self.bits, s0, s1)
+
+    def compute_rect(self, rows, cols):
+        import torch
+        if rows[0] >= rows[1] or cols[0] >= cols[1]:
+            return
+        ready = torch.cuda.Event()
+        ready.record()                       # after zeroing + every prepare so far
+        stream = self.streams[self.launches % len(self.streams)]
+        stream.wait_event(ready)
+        self.ctx.compute_king_rect(self.sm, self.wps, rows, cols, self.thr,
+                                   self.max_results, self.results,
+                                   self.index_flag[0:1], self.index_flag[1:2],
+                                   stream=stream)
+        self.launches += 1
+
+    def finish(self):
+        import torch
+        cur = torch.cuda.current_stream()
+        for s in self.streams:
+            cur.wait_stream(s)
+        count, overflow = (int(x) & 0xFFFFFFFF for x in self.index_flag.tolist())
+        return self.results, min(count, self.max_results), int(overflow)

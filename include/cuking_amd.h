@@ -193,6 +193,27 @@ cuking_status cuking_compute_king_tiles(
     float kin_threshold, uint32_t max_results, cuking_result *d_results,
     uint32_t *d_result_index, uint32_t *d_result_overflow, void *stream);
 
+/* Staged form of the same operator for a DIAGONAL block (rows == columns),
+ * used when the bitset arrives in pieces (e.g. a chunked RCCL broadcast):
+ * cuking_prepare_samples() converts samples [sample_begin, sample_end) (global
+ * indices, tile aligned except at the block end) into the context's kernel
+ * layout; cuking_compute_king_rect() then evaluates the pairs (i < j) of rows
+ * [row_begin, row_end) x columns [col_begin, col_end) whose samples have all
+ * been prepared.  Rectangles that tile the upper triangle reproduce
+ * cuking_compute_king() exactly.  Both are asynchronous on `stream`; kernels
+ * of different rectangles may run concurrently on different streams (they only
+ * read the prepared layout and append atomically). */
+cuking_status cuking_prepare_samples(cuking_ctx *ctx, const cuking_submatrix *sm,
+                                     uint32_t words_per_sample,
+                                     const uint64_t *d_bit_sets,
+                                     uint32_t sample_begin, uint32_t sample_end,
+                                     void *stream);
+cuking_status cuking_compute_king_rect(
+    cuking_ctx *ctx, const cuking_submatrix *sm, uint32_t words_per_sample,
+    uint32_t row_begin, uint32_t row_end, uint32_t col_begin, uint32_t col_end,
+    float kin_threshold, uint32_t max_results, cuking_result *d_results,
+    uint32_t *d_result_index, uint32_t *d_result_overflow, void *stream);
+
 /* Diagnostic: the six sums of every pair, no threshold.  d_counts holds
  * NumRows x NumCols records, pair (i, j) at [(i - i_begin) * NumCols +
  * (j - j_begin)]; entries with i >= j are left untouched. */

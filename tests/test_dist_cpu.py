@@ -27,6 +27,77 @@ def _free_port():
         return s.getsockname()[1]
 
 
+class OracleStagedOps:
+    """Stand-in for GpuStagedOps: the oracle evaluates each rectangle, and only
+    from samples that have been 'prepared' (i.e. have arrived)."""
+
+    def __init__(self, pyoracle, bits, thr, max_results):
+        self.o, self.bits, self.thr, self.max_results = pyoracle, bits, thr, max_results
+
+    def begin(self):
+        self.recs, self.prepared = [], np.zeros(self.bits.shape[0], dtype=bool)
+        self.snapshot = np.zeros_like(self.bits.numpy().view(np.uint64))
+
+    def prepare(self, s0, s1):
+        self.snapshot[s0:s1] = self.bits.numpy().view(np.uint64)[s0:s1]
+        self.prepared[s0:s1] = True
+
+    def compute_rect(self, rows, cols):
+        (r0, r1), (c0, c1) = rows, cols
+        assert self.prepared[r0:r1].all() and self.prepared[c0:c1].all()
+        # split into diagonal part and the part strictly right of it
+        if c0 < r1:   # overlaps the rows: [r0,r1) x [c0,c1) with i<j
+            lo, hi = min(r0, c0), max(r1, c1)
+            osm = self.o.Submatrix(lo, hi, lo, hi)
+            r, _, _ = self.o.compute(osm, np.ascontiguousarray(self.snapshot[lo:hi]), self.thr)
+            keep = ((r["sample_i"] >= r0) & (r["sample_i"] < r1) &
+                    (r["sample_j"] >= c0) & (r["sample_j"] < c1))
+            self.recs.append(r[keep])
+        else:
+            osm = self.o.Submatrix(r0, r1, c0, c1)
+            sub = np.concatenate([self.snapshot[r0:r1], self.snapshot[c0:c1]])
+            self.recs.append(self.o.compute(osm, np.ascontiguousarray(sub), self.thr)[0])
+
+    def finish(self):
+        recs = (np.concatenate(self.recs) if self.recs
+                else np.zeros(0, dtype=self.o.RESULT_DTYPE))
+        count = len(recs)
+        overflow = int(count > self.max_results)
+        keep = min(count, self.max_results)
+        buf = torch.zeros((max(self.max_results, 1), 6), dtype=torch.int32)
+        if keep:
+            buf[:keep] = torch.from_numpy(
+                recs[:keep].view(np.uint32).reshape(-1, 6).view(np.int32).copy())
+        return buf, keep, overflow
+
+
+def _staged_worker(rank, world, port, n, m, thr, chunks, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cuking_amd
+    from cuking_amd.dist import all_pairs_king_staged
+    from oracle import pyoracle
+    from conftest import random_genotypes
+    wps = cuking_amd.words_per_sample(m)
+    bits = torch.zeros((n, wps), dtype=torch.int64)
+    if rank == 0:
+        geno = random_genotypes(np.random.default_rng(2), n, m, missing=0.05)
+        geno[n - 1] = geno[0]
+        geno[n // 3] = geno[n // 2]
+        bits.copy_(torch.from_numpy(pyoracle.bitset_from_genotypes(geno).view(np.int64)))
+    ops = OracleStagedOps(pyoracle, bits, thr, 100000)
+    merged, (ra, rb) = all_pairs_king_staged(ops, n, 64, bits, num_chunks=chunks)
+    if rank == 0:
+        host = np.ascontiguousarray(bits.numpy().view(np.uint64))
+        exp, _, _ = pyoracle.compute(pyoracle.submatrix(n), host, thr)
+        Path(out_path).write_text(f"{int(merged.tobytes() == exp.tobytes())} {len(exp)}")
+    else:
+        assert merged is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _worker(rank, world, port, n, m, thr, max_results, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -109,3 +180,39 @@ def test_overflow_on_any_rank_fails_everywhere(tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), 200, 300, -5.0, 50, str(out)),
              nprocs=2, join=True)
     assert out.read_text().split()[0] == "overflow"
+
+
+@pytest.mark.parametrize("world,chunks", [(2, 3), (3, 5)])
+def test_staged_overlapped_pass_equals_single_pass(tmp_path, world, chunks):
+    """Chunked broadcast + row bands + rectangles-as-chunks-arrive (gloo)."""
+    out = tmp_path / "result.txt"
+    mp.spawn(_staged_worker, args=(world, _free_port(), 330, 200, -0.1, chunks, str(out)),
+             nprocs=world, join=True)
+    same, n_exp = out.read_text().split()
+    assert same == "1" and int(n_exp) > 100
+
+
+@pytest.mark.parametrize("n,tile,world,chunks", [(300, 64, 3, 4), (1000, 64, 8, 8),
+                                                 (130, 64, 2, 8), (64, 64, 2, 3),
+                                                 (2000, 128, 4, 5), (65, 64, 8, 8)])
+def test_staged_schedule_covers_every_pair_once(n, tile, world, chunks):
+    from cuking_amd.dist import row_partition, staged_schedule
+    cover = np.zeros((n, n), dtype=np.int32)
+    for r in range(world):
+        (ra, rb), steps = staged_schedule(n, tile, world, r, chunks)
+        for (c0, c1), rect in steps:
+            if rect is None:
+                continue
+            (r0, r1), (q0, q1) = rect
+            assert ra <= r0 and r1 <= rb
+            assert r1 <= c1 and q1 <= c1      # only samples that have arrived
+            assert r0 % tile == 0 and q0 % tile == 0
+            I, J = np.meshgrid(np.arange(r0, r1), np.arange(q0, q1), indexing="ij")
+            cover[I[I < J], J[I < J]] += 1
+    assert np.all(cover[np.triu_indices(n, 1)] == 1)
+    assert cover.sum() == n * (n - 1) // 2
+    t = (n + tile - 1) // tile
+    sizes = [sum(t - r for r in range(a, b)) for a, b in row_partition(t, world)]
+    assert sum(sizes) == t * (t + 1) // 2
+    if t >= 8 * world:
+        assert max(sizes) <= 1.15 * (sum(sizes) / world)

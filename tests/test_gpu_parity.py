@@ -164,6 +164,68 @@ def test_tile_ranges_union(ctx, oracle, variant):
         ctx.run(sm, bits.shape[1], d_bits, -0.05, tile_range=(0, tiles + 1))
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("world,chunks", [(1, 1), (1, 4), (2, 3), (3, 8), (8, 5)])
+def test_staged_rectangles_union(ctx, oracle, variant, world, chunks):
+    """The overlapped multi-GPU schedule (chunked arrival, row bands, rectangle
+    launches on side streams) replayed rank by rank on one GPU == oracle."""
+    import torch
+    from cuking_amd.dist import GpuStagedOps, staged_schedule
+    select(ctx, "tiled", variant)
+    rng = np.random.default_rng(31)
+    n, m = 700, 333
+    geno = random_genotypes(rng, n, m, missing=0.04)
+    geno[650] = geno[3]
+    geno[699] = geno[320]
+    bits = oracle.bitset_from_genotypes(geno)
+    exp, _, _ = oracle.compute(oracle.submatrix(n), bits, -0.08)
+    sm = cuking_amd.Submatrix(n)
+    tile = ctx.tile_samples()
+    parts = []
+    for rank in range(world):
+        # the receive buffer starts as garbage and fills chunk by chunk
+        d_bits = torch.full((n, bits.shape[1]), 0x5A5A5A5A5A5A5A5A, dtype=torch.int64,
+                            device="cuda:0")
+        src = torch.from_numpy(bits.view(np.int64))
+        ops = GpuStagedOps(ctx, sm, bits.shape[1], d_bits, -0.08, 200000)
+        ops.begin()
+        (ra, rb), steps = staged_schedule(n, tile, world, rank, chunks)
+        for (c0, c1), rect in steps:
+            d_bits[c0:c1].copy_(src[c0:c1])          # "chunk arrives"
+            if rect is None:
+                continue
+            ops.prepare(c0, c1)
+            ops.compute_rect(*rect)
+        res, count, ovf = ops.finish()
+        assert ovf == 0
+        parts.append(res[:count].cpu().numpy().view(np.uint32).reshape(-1).view(
+            cuking_amd.KING_RESULT_DTYPE).copy())
+    merged = cuking_amd.sort_results(np.ascontiguousarray(np.concatenate(parts)))
+    assert merged.tobytes() == exp.tobytes()
+
+
+def test_staged_api_errors(ctx, oracle):
+    import torch
+    select(ctx, "tiled", 0)
+    n = 200
+    bits = oracle.bitset_from_genotypes(random_genotypes(np.random.default_rng(1), n, 100))
+    d_bits = ctx.upload_bitset(bits)
+    sm = cuking_amd.Submatrix(n)
+    res = torch.zeros((10, 6), dtype=torch.int32, device="cuda:0")
+    idx = torch.zeros(2, dtype=torch.int32, device="cuda:0")
+    with pytest.raises(cuking_amd.CukingError):      # not tile aligned
+        ctx.prepare_samples(sm, bits.shape[1], d_bits, 10, 200)
+    with pytest.raises(cuking_amd.CukingError):      # outside the block
+        ctx.prepare_samples(sm, bits.shape[1], d_bits, 0, 264)
+    off = cuking_amd.Submatrix(n, 2, 1)              # off-diagonal block
+    with pytest.raises(cuking_amd.CukingError):
+        ctx.prepare_samples(off, bits.shape[1], d_bits, 0, 100)
+    ctx.prepare_samples(sm, bits.shape[1], d_bits, 0, 200)
+    with pytest.raises(cuking_amd.CukingError):
+        ctx.compute_king_rect(sm, bits.shape[1], (0, 100), (0, 200), 0.0, 10, res,
+                              idx[0:1], idx[1:2])
+
+
 @pytest.mark.parametrize("kernel,variant", [("stream", 0), ("tiled", 0)])
 def test_result_overflow(ctx, oracle, kernel, variant):
     """cuking.cu:297-313, :747-751: overflow is an error, never truncation."""
