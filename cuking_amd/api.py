@@ -216,14 +216,16 @@ class KingContext:
             _stream_handle(stream)))
 
     def compute_king_rect(self, submatrix: Submatrix, words_per_sample: int,
-                          rows, cols, kin_threshold: float, max_results: int,
-                          results, result_index, result_overflow,
-                          stream=None) -> None:
+                          bit_sets, rows, cols, kin_threshold: float,
+                          max_results: int, results, result_index,
+                          result_overflow, stream=None) -> None:
         """Staged operator, step 2: pairs (i < j) of rows x cols (sample index
         ranges) from the prepared layout; appends like compute_king."""
+        self._check_bits(submatrix, words_per_sample, bit_sets)
         assert results.numel() * results.element_size() >= max_results * 24
         check(self.lib.cuking_compute_king_rect(
-            self.handle, C.byref(submatrix.c), words_per_sample, rows[0],
+            self.handle, C.byref(submatrix.c), words_per_sample,
+            bit_sets.data_ptr(), rows[0],
             rows[1], cols[0], cols[1], kin_threshold, max_results,
             results.data_ptr(), result_index.data_ptr(),
             result_overflow.data_ptr(), _stream_handle(stream)))

@@ -46,7 +46,10 @@ def _newer(target: Path, deps) -> bool:
     return all(Path(d).stat().st_mtime <= t for d in deps)
 
 
-def build_library(force: bool = False, save_temps: bool = False) -> Path:
+def build_library(force: bool = False, save_temps: bool = False,
+                  tuning: bool = False) -> Path:
+    """tuning=True adds timing-only experiment kernels (-DCUKING_TUNING); never
+    the shipped configuration (build() and the tests use the default)."""
     srcs = [CSRC / s for s in HIP_SOURCES]
     deps = srcs + [CSRC / "king_common.h", INCLUDE / "cuking_amd.h",
                    Path(__file__)]
@@ -54,6 +57,8 @@ def build_library(force: bool = False, save_temps: bool = False) -> Path:
         return LIB_PATH
     cmd = [_hipcc(), *HIP_FLAGS, "-shared", f"-I{INCLUDE}", f"-I{CSRC}",
            *map(str, srcs), "-o", str(LIB_PATH)]
+    if tuning:
+        cmd.insert(1, "-DCUKING_TUNING")
     cwd = PKG
     if save_temps:  # keeps the .s / resource-usage remarks for inspection
         cwd = PKG / "build_tmp"
@@ -103,8 +108,10 @@ def main(argv=None) -> int:
     ap.add_argument("--lib", action="store_true", help="library only")
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--save-temps", action="store_true")
+    ap.add_argument("--tuning", action="store_true")
     args = ap.parse_args(argv)
-    print(build_library(force=args.force, save_temps=args.save_temps))
+    print(build_library(force=args.force or args.tuning, save_temps=args.save_temps,
+                        tuning=args.tuning))
     if not args.lib:
         print(build_cli(force=args.force))
     return 0

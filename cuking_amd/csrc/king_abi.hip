@@ -97,6 +97,7 @@ struct cuking_ctx {
   cuking_kernel kernel = CUKING_KERNEL_TILED;
   int variant = 0;
   uint32_t band_rows = 16;
+  int counts_mode = -1;  // -1 auto, 0 lean (4 sums + recount), 1 full (5 sums)
 
   // Workspace of the tiled kernel: the k-major planes and the band prefix.
   uint4 *planes = nullptr;
@@ -117,6 +118,15 @@ int default_variant() {
     if (k >= 0 && k < kNumTiledVariants) return k;
   }
   return 0;
+}
+
+// Which form of the tiled kernel: the lean one unless (nearly) every pair will
+// be emitted -- a threshold at or below zero passes about half of all
+// unrelated pairs -- or the caller forces one.
+bool use_full_counts(const cuking_ctx *ctx, float kin_threshold, bool dense) {
+  if (dense || ctx->counts_mode == 1) return true;
+  if (ctx->counts_mode == 0) return false;
+  return !(kin_threshold > 0.0f);
 }
 
 cuking_status bind(cuking_ctx *ctx) {
@@ -269,10 +279,14 @@ cuking_status run_tiled(cuking_ctx *ctx, const cuking_submatrix &sm,
   a.result_overflow = d_result_overflow;
   a.dense_counts = d_counts;
   a.rect_rows = a.rect_row0 = a.rect_col0 = 0;
+  a.bits = d_bit_sets;
+  a.words_per_sample = words_per_sample;
 
   EventPair *ev = nullptr;
   if (ctx->timing) HIP_TRY(ctx->king_timer.begin(stream, &ev));
-  HIP_TRY(launch_tiled(ctx->variant, a, tile_end - tile_begin, stream));
+  HIP_TRY(launch_tiled(ctx->variant,
+                       use_full_counts(ctx, kin_threshold, d_counts != nullptr), a,
+                       tile_end - tile_begin, stream));
   if (ev) HIP_TRY(hipEventRecord(ev->stop, stream));
   return CUKING_OK;
 }
@@ -483,6 +497,12 @@ cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
     if (value < 1 || value > 64)
       return fail(CUKING_ERR_INVALID_ARGUMENT, "band_rows outside [1, 64]");
     ctx->band_rows = (uint32_t)value;
+    return CUKING_OK;
+  }
+  if (strcmp(key, "counts_mode") == 0) {
+    if (value < -1 || value > 1)
+      return fail(CUKING_ERR_INVALID_ARGUMENT, "counts_mode outside [-1, 1]");
+    ctx->counts_mode = (int)value;
     return CUKING_OK;
   }
   return fail(CUKING_ERR_INVALID_ARGUMENT, "unknown option %s", key);
@@ -720,12 +740,12 @@ cuking_status cuking_prepare_samples(cuking_ctx *ctx, const cuking_submatrix *sm
 
 cuking_status cuking_compute_king_rect(
     cuking_ctx *ctx, const cuking_submatrix *sm, uint32_t words_per_sample,
-    uint32_t row_begin, uint32_t row_end, uint32_t col_begin, uint32_t col_end,
+    const uint64_t *d_bit_sets, uint32_t row_begin, uint32_t row_end, uint32_t col_begin, uint32_t col_end,
     float kin_threshold, uint32_t max_results, cuking_result *d_results,
     uint32_t *d_result_index, uint32_t *d_result_overflow, void *stream) {
   cuking_status st = bind(ctx);
   if (st != CUKING_OK) return st;
-  st = check_block(sm, words_per_sample);
+  st = check_compute_args(sm, words_per_sample, d_bit_sets);
   if (st != CUKING_OK) return st;
   if (!sm_is_diag(*sm))
     return fail(CUKING_ERR_INVALID_ARGUMENT,
@@ -763,10 +783,12 @@ cuking_status cuking_compute_king_rect(
   a.result_index = d_result_index;
   a.result_overflow = d_result_overflow;
   a.dense_counts = nullptr;
+  a.bits = d_bit_sets;
+  a.words_per_sample = words_per_sample;
   EventPair *ev = nullptr;
   if (ctx->timing) HIP_TRY(ctx->king_timer.begin((hipStream_t)stream, &ev));
-  HIP_TRY(launch_tiled(ctx->variant, a, (uint64_t)(r1 - r0) * (c1 - c0),
-                       (hipStream_t)stream));
+  HIP_TRY(launch_tiled(ctx->variant, use_full_counts(ctx, kin_threshold, false), a,
+                       (uint64_t)(r1 - r0) * (c1 - c0), (hipStream_t)stream));
   if (ev) HIP_TRY(hipEventRecord(ev->stop, (hipStream_t)stream));
   return CUKING_OK;
 }

@@ -102,6 +102,10 @@ struct TiledArgs {
   uint32_t *result_index;
   uint32_t *result_overflow;
   cuking_counts *dense_counts;  // non-null: diagnostic mode, no threshold
+  // Reference-layout bitset of the block (the lean kernel recounts hom/hom
+  // sites from it for the pairs it emits).
+  const uint64_t *bits;
+  uint32_t words_per_sample;
 };
 
 // One compiled shape of the tiled kernel.
@@ -113,11 +117,19 @@ struct TiledVariant {
   uint32_t lds_bytes; // dynamic LDS
 };
 
+#ifdef CUKING_TUNING
+constexpr int kNumTiledVariants = 10;  // + timing-only experiments
+#else
 constexpr int kNumTiledVariants = 4;
+#endif
 const TiledVariant &tiled_variant(int v);
 // Enqueues tiles [args.tile_begin, args.tile_begin + num_tiles).
-hipError_t launch_tiled(int variant, const TiledArgs &args, uint64_t num_tiles,
-                        hipStream_t stream);
+// full = accumulate all five sums for every pair (needed for the diagnostic
+// counts; chosen when nearly every pair is expected to pass the threshold);
+// otherwise the lean form: four sums in the main loop, IBS2 recounted for
+// emitted pairs only.  Same records either way.
+hipError_t launch_tiled(int variant, bool full, const TiledArgs &args,
+                        uint64_t num_tiles, hipStream_t stream);
 
 // Converts plane-sample tiles [s_tile_begin, s_tile_end) (units of 64 plane
 // samples) of the block.

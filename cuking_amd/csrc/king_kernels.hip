@@ -58,6 +58,23 @@ __device__ __forceinline__ void emit_result(uint32_t i, uint32_t j, float kin,
   }
 }
 
+// Sites where both samples are homozygous (hom-ref or hom-alt), counted by one
+// whole wavefront straight from the reference layout: ~het is "homozygous and
+// defined" (missing and padding sites have the het bit set, cuking.cu:688-697).
+// Every lane gets the sum.
+__device__ __forceinline__ uint32_t wave_hom_hom_count(
+    const uint64_t *__restrict__ bits, uint32_t words_per_sample,
+    uint32_t offset_i, uint32_t offset_j, uint32_t lane) {
+  const uint32_t n = words_per_sample / 2;
+  const uint64_t *het_i = bits + (uint64_t)offset_i * words_per_sample;
+  const uint64_t *het_j = bits + (uint64_t)offset_j * words_per_sample;
+  uint32_t c = 0;
+  for (uint32_t w = lane; w < n; w += 64) c += __popcll(~(het_i[w] | het_j[w]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+  return c;
+}
+
 // ---------------------------------------------------------------------------
 // prepare_planes_kernel
 // One workgroup: 64 plane-samples x 16 source words (= 32 k-rows).  Reads are
@@ -141,7 +158,8 @@ __global__ __launch_bounds__(256) void prepare_planes_kernel(
 //     het_i = hi, het_j = hj, both_het = bh, opposing_hom = opp,
 //     concordant_hom = hh - opp, shared = hi + hj - bh + hh.
 // ---------------------------------------------------------------------------
-template <int TIT, int TJT, int RI, int RJ, int KC, int KU, int MINW>
+template <int TIT, int TJT, int RI, int RJ, int KC, int KU, int MINW, bool FULL,
+          int ABLATE = 0>
 __global__ __launch_bounds__(TIT *TJT, MINW) void king_tiled_kernel(
     const TiledArgs a) {
   constexpr int TILE = TIT * RI;
@@ -200,6 +218,7 @@ __global__ __launch_bounds__(TIT *TJT, MINW) void king_tiled_kernel(
     }
   };
 
+  // hh is only accumulated by the FULL form (dead registers otherwise).
   uint32_t c_hh[RI][RJ], c_opp[RI][RJ], c_bh[RI][RJ], c_hi[RI][RJ],
       c_hj[RI][RJ];
 #pragma unroll
@@ -213,9 +232,13 @@ __global__ __launch_bounds__(TIT *TJT, MINW) void king_tiled_kernel(
     const uint32_t buf = chunk & 1;
     // Chunk `chunk` has landed (vmcnt) for every wave, and every wave is done
     // reading the other buffer.
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), leaves lgkmcnt/expcnt
-    __syncthreads();
-    if (chunk + 1 < num_chunks) issue_chunk(chunk + 1, buf ^ 1);
+    // (ABLATE: timing-only experiments of the tuning build; results are
+    // wrong.  bit 0 = no per-step LDS reads, bit 1 = no DMA and no barrier.)
+    if (!(ABLATE & 2)) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), leaves lgkmcnt/expcnt
+      __syncthreads();
+      if (chunk + 1 < num_chunks) issue_chunk(chunk + 1, buf ^ 1);
+    }
 
     const uint4 *l_rows = lds + (buf * 2 + 0) * KC * TILE;
     const uint4 *l_cols = lds + (buf * 2 + 1) * KC * TILE;
@@ -224,16 +247,25 @@ __global__ __launch_bounds__(TIT *TJT, MINW) void king_tiled_kernel(
 #pragma unroll(KU)
     for (int kc = 0; kc < KC; ++kc) {
       uint4 ri[RI], cj[RJ];
+      const int kr = (ABLATE & 1) ? 0 : kc;
 #pragma unroll
-      for (int x = 0; x < RI; ++x) ri[x] = l_rows[kc * TILE + x * TIT + ti];
+      for (int x = 0; x < RI; ++x) ri[x] = l_rows[kr * TILE + x * TIT + ti];
 #pragma unroll
-      for (int y = 0; y < RJ; ++y) cj[y] = l_cols[kc * TILE + y * TJT + tj];
+      for (int y = 0; y < RJ; ++y) cj[y] = l_cols[kr * TILE + y * TJT + tj];
+      if (ABLATE & 1) {  // keep the logic ops from being hoisted
+#pragma unroll
+        for (int x = 0; x < RI; ++x)
+          asm volatile("" : "+v"(ri[x].x), "+v"(ri[x].y), "+v"(ri[x].z), "+v"(ri[x].w));
+#pragma unroll
+        for (int y = 0; y < RJ; ++y)
+          asm volatile("" : "+v"(cj[y].x), "+v"(cj[y].y), "+v"(cj[y].z), "+v"(cj[y].w));
+      }
 #pragma unroll
       for (int x = 0; x < RI; ++x) {
 #pragma unroll
         for (int y = 0; y < RJ; ++y) {
           const uint32_t hom_both = ri[x].z & cj[y].z;
-          c_hh[x][y] += __builtin_popcount(hom_both);
+          if (FULL) c_hh[x][y] += __builtin_popcount(hom_both);
           c_opp[x][y] += __builtin_popcount(
               __builtin_amdgcn_bitop3_b32(ri[x].y, cj[y].y, hom_both, 0x28));
           c_bh[x][y] += __builtin_popcount(ri[x].x & cj[y].x);
@@ -248,34 +280,61 @@ __global__ __launch_bounds__(TIT *TJT, MINW) void king_tiled_kernel(
 #pragma unroll
   for (int x = 0; x < RI; ++x) {
     const uint32_t li = tr * TILE + x * TIT + ti;  // row inside the block
-    if (li >= a.geo.num_rows) continue;
     const uint32_t i = a.i_begin + li;
 #pragma unroll
     for (int y = 0; y < RJ; ++y) {
       const uint32_t lj = tc * TILE + y * TJT + tj;
-      if (lj >= a.geo.num_cols) continue;
       const uint32_t j = a.j_begin + lj;
-      if (i >= j) continue;  // cuking.cu:199
+      // cuking.cu:199 plus the tile padding
+      const bool valid = li < a.geo.num_rows && lj < a.geo.num_cols && i < j;
       const uint32_t het_i = c_hi[x][y], het_j = c_hj[x][y];
       const uint32_t both_het = c_bh[x][y], opp = c_opp[x][y];
-      const uint32_t conc = c_hh[x][y] - opp;
-      const uint32_t shared = het_i + het_j - both_het + c_hh[x][y];
-      if (a.dense_counts != nullptr) {
-        cuking_counts c;
-        c.het_i = het_i;
-        c.het_j = het_j;
-        c.both_het = both_het;
-        c.opposing_hom = opp;
-        c.concordant_hom = conc;
-        c.shared = shared;
-        a.dense_counts[(uint64_t)li * a.geo.num_cols + lj] = c;
-        continue;
-      }
-      const float kin = king_kinship(het_i, het_j, both_het, opp);
-      if (kin > a.kin_threshold) {
-        const uint32_t ibs0 = opp, ibs2 = conc + both_het;
-        emit_result(i, j, kin, ibs0, shared - ibs0 - ibs2, ibs2, a.max_results,
-                    a.results, a.result_index, a.result_overflow);
+      if (FULL) {
+        if (!valid) continue;
+        const uint32_t conc = c_hh[x][y] - opp;
+        const uint32_t shared = het_i + het_j - both_het + c_hh[x][y];
+        if (a.dense_counts != nullptr) {
+          cuking_counts c;
+          c.het_i = het_i;
+          c.het_j = het_j;
+          c.both_het = both_het;
+          c.opposing_hom = opp;
+          c.concordant_hom = conc;
+          c.shared = shared;
+          a.dense_counts[(uint64_t)li * a.geo.num_cols + lj] = c;
+          continue;
+        }
+        const float kin = king_kinship(het_i, het_j, both_het, opp);
+        if (kin > a.kin_threshold) {
+          const uint32_t ibs0 = opp, ibs2 = conc + both_het;
+          emit_result(i, j, kin, ibs0, shared - ibs0 - ibs2, ibs2, a.max_results,
+                      a.results, a.result_index, a.result_overflow);
+        }
+      } else {
+        // Lean pass: the main loop kept the four sums kinship needs.  IBS0 and
+        // IBS1 follow from them (ibs1 = exactly one het = hi + hj - 2 bh);
+        // IBS2 needs the hom/hom count, which the whole wavefront now sums
+        // for each of the (few) pairs that pass the threshold.
+        const float kin = king_kinship(het_i, het_j, both_het, opp);
+        const bool emit = valid && kin > a.kin_threshold;
+        unsigned long long pending = __ballot(emit);  // wave-uniform
+        uint32_t hom_hom = 0;
+        while (pending) {
+          const int src = __builtin_ctzll(pending);
+          pending &= pending - 1;
+          const uint32_t p_li = __builtin_amdgcn_readlane(li, src);
+          const uint32_t p_lj = __builtin_amdgcn_readlane(lj, src);
+          const uint32_t off_j = a.geo.diag ? p_lj : a.geo.num_rows + p_lj;
+          const uint32_t sum = wave_hom_hom_count(a.bits, a.words_per_sample,
+                                                  p_li, off_j, lane);
+          if ((int)lane == src) hom_hom = sum;
+        }
+        if (emit) {
+          const uint32_t ibs0 = opp, ibs2 = hom_hom - opp + both_het;
+          emit_result(i, j, kin, ibs0, het_i + het_j - 2 * both_het, ibs2,
+                      a.max_results, a.results, a.result_index,
+                      a.result_overflow);
+        }
       }
     }
   }
@@ -396,10 +455,11 @@ __global__ __launch_bounds__(256) void pack_kernel(
   if (bad) atomicOr(status, bad);
 }
 
-template <int TIT, int TJT, int RI, int RJ, int KC, int KU, int MINW>
+template <int TIT, int TJT, int RI, int RJ, int KC, int KU, int MINW, bool FULL,
+          int ABLATE = 0>
 hipError_t launch_variant(const TiledArgs &args, uint64_t num_tiles,
                           uint32_t lds_bytes, hipStream_t stream) {
-  auto kernel = king_tiled_kernel<TIT, TJT, RI, RJ, KC, KU, MINW>;
+  auto kernel = king_tiled_kernel<TIT, TJT, RI, RJ, KC, KU, MINW, FULL, ABLATE>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(
@@ -428,23 +488,43 @@ const TiledVariant kVariants[kNumTiledVariants] = {
     {"t128_r8x4_k8_w2", 128, 8, 512, 2 * 2 * 8 * 128 * 16},
     {"t128_r4x4_k8_w4", 128, 8, 1024, 2 * 2 * 8 * 128 * 16},
     {"t64_r4x4_k16_w4", 64, 16, 256, 2 * 2 * 16 * 64 * 16},
+#ifdef CUKING_TUNING
+    {"ablate_noldsread", 64, 8, 256, 2 * 2 * 8 * 64 * 16},
+    {"ablate_nodma_nobarrier", 64, 8, 256, 2 * 2 * 8 * 64 * 16},
+    {"ablate_both", 64, 8, 256, 2 * 2 * 8 * 64 * 16},
+    {"t64_r4x4_k8_u4", 64, 8, 256, 2 * 2 * 8 * 64 * 16},
+    {"t64_r4x4_k8_u1", 64, 8, 256, 2 * 2 * 8 * 64 * 16},
+    {"t64_r4x4_k8_w5", 64, 8, 256, 2 * 2 * 8 * 64 * 16},
+#endif
 };
 
 }  // namespace
 
 const TiledVariant &tiled_variant(int v) { return kVariants[v]; }
 
-hipError_t launch_tiled(int variant, const TiledArgs &args, uint64_t num_tiles,
-                        hipStream_t stream) {
+hipError_t launch_tiled(int variant, bool full, const TiledArgs &args,
+                        uint64_t num_tiles, hipStream_t stream) {
   if (num_tiles == 0) return hipSuccess;
   const uint32_t lds = kVariants[variant].lds_bytes;
+#define CUKING_SHAPE(...)                                                      \
+  (full ? launch_variant<__VA_ARGS__, true>(args, num_tiles, lds, stream)      \
+        : launch_variant<__VA_ARGS__, false>(args, num_tiles, lds, stream))
   switch (variant) {
-    case 0: return launch_variant<16, 16, 4, 4, 8, 2, 4>(args, num_tiles, lds, stream);
-    case 1: return launch_variant<16, 32, 8, 4, 8, 2, 2>(args, num_tiles, lds, stream);
-    case 2: return launch_variant<32, 32, 4, 4, 8, 2, 4>(args, num_tiles, lds, stream);
-    case 3: return launch_variant<16, 16, 4, 4, 16, 2, 4>(args, num_tiles, lds, stream);
+    case 0: return CUKING_SHAPE(16, 16, 4, 4, 8, 2, 4);
+    case 1: return CUKING_SHAPE(16, 32, 8, 4, 8, 2, 2);
+    case 2: return CUKING_SHAPE(32, 32, 4, 4, 8, 2, 4);
+    case 3: return CUKING_SHAPE(16, 16, 4, 4, 16, 2, 4);
+#ifdef CUKING_TUNING
+    case 4: return launch_variant<16, 16, 4, 4, 8, 2, 4, false, 1>(args, num_tiles, lds, stream);
+    case 5: return launch_variant<16, 16, 4, 4, 8, 2, 4, false, 2>(args, num_tiles, lds, stream);
+    case 6: return launch_variant<16, 16, 4, 4, 8, 2, 4, false, 3>(args, num_tiles, lds, stream);
+    case 7: return launch_variant<16, 16, 4, 4, 8, 4, 4, false>(args, num_tiles, lds, stream);
+    case 8: return launch_variant<16, 16, 4, 4, 8, 1, 4, false>(args, num_tiles, lds, stream);
+    case 9: return launch_variant<16, 16, 4, 4, 8, 2, 5, false>(args, num_tiles, lds, stream);
+#endif
     default: return hipErrorInvalidValue;
   }
+#undef CUKING_SHAPE
 }
 
 hipError_t launch_prepare_planes(const uint64_t *d_bit_sets,

@@ -229,7 +229,7 @@ class GpuStagedOps:
         ready.record()                       # after zeroing + every prepare so far
         stream = self.streams[self.launches % len(self.streams)]
         stream.wait_event(ready)
-        self.ctx.compute_king_rect(self.sm, self.wps, rows, cols, self.thr,
+        self.ctx.compute_king_rect(self.sm, self.wps, self.bits, rows, cols, self.thr,
                                    self.max_results, self.results,
                                    self.index_flag[0:1], self.index_flag[1:2],
                                    stream=stream)

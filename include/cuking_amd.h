@@ -144,9 +144,12 @@ typedef enum cuking_kernel {
 } cuking_kernel;
 cuking_status cuking_ctx_set_kernel(cuking_ctx *ctx, cuking_kernel kernel);
 /* Tuning knobs of the tiled kernel: "variant" (compiled tile shape, 0 ..
- * cuking_num_variants()-1; also env CUKING_AMD_VARIANT) and "band_rows"
- * (tile-rows per scheduling band, 1..64; env CUKING_AMD_BAND_ROWS).  Results
- * do not depend on either. */
+ * cuking_num_variants()-1; also env CUKING_AMD_VARIANT), "band_rows"
+ * (tile-rows per scheduling band, 1..64; env CUKING_AMD_BAND_ROWS) and
+ * "counts_mode" (0 = lean: four sums per pair in the main loop, the hom/hom
+ * count behind IBS2 recounted only for emitted pairs; 1 = full: all five sums
+ * for every pair; -1 = automatic: lean when kin_threshold > 0).  Results do
+ * not depend on any of them. */
 cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
                                     int64_t value);
 int cuking_num_variants(void);
@@ -210,7 +213,7 @@ cuking_status cuking_prepare_samples(cuking_ctx *ctx, const cuking_submatrix *sm
                                      void *stream);
 cuking_status cuking_compute_king_rect(
     cuking_ctx *ctx, const cuking_submatrix *sm, uint32_t words_per_sample,
-    uint32_t row_begin, uint32_t row_end, uint32_t col_begin, uint32_t col_end,
+    const uint64_t *d_bit_sets, uint32_t row_begin, uint32_t row_end, uint32_t col_begin, uint32_t col_end,
     float kin_threshold, uint32_t max_results, cuking_result *d_results,
     uint32_t *d_result_index, uint32_t *d_result_overflow, void *stream);
 

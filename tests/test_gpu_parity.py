@@ -21,8 +21,9 @@ pytestmark = pytest.mark.gpu
 KERNELS = [("stream", 0)] + [("tiled", v) for v in range(4)]
 
 
-def select(ctx, kernel, variant):
+def select(ctx, kernel, variant, counts_mode=-1):
     ctx.set_kernel(kernel)
+    ctx.set_option("counts_mode", counts_mode)
     if kernel == "tiled":
         ctx.set_option("variant", variant)
 
@@ -112,6 +113,27 @@ def test_thresholded_records_bit_exact(ctx, oracle, kernel, variant, thr):
     assert got.tobytes() == exp.tobytes()   # i, j, kin bits, ibs0/1/2
 
 
+@pytest.mark.parametrize("variant", range(4))
+@pytest.mark.parametrize("counts_mode", [0, 1])
+@pytest.mark.parametrize("thr", [-1e30, 0.0, 0.1])
+def test_lean_and_full_forms_agree_with_oracle(ctx, oracle, variant, counts_mode, thr):
+    """counts_mode 0 = four sums + in-wave IBS2 recount for emitted pairs (here
+    forced even when every pair is emitted), 1 = five sums for every pair."""
+    select(ctx, "tiled", variant, counts_mode)
+    rng = np.random.default_rng(123)
+    for n, m, k, shard in ((97, 50, 1, 0), (200, 1300, 1, 0), (300, 257, 2, 1)):
+        geno = random_genotypes(rng, n, m, missing=0.08)
+        geno[n - 1] = geno[0]
+        geno[n // 2] = -1
+        osm = oracle.submatrix(n, k, shard)
+        bits = oracle.bitset_from_genotypes(geno, osm)
+        exp, _, _ = oracle.compute(osm, bits, thr)
+        got = ctx.run(cuking_amd.Submatrix(n, k, shard), bits.shape[1],
+                      ctx.upload_bitset(bits), thr)
+        assert got.tobytes() == exp.tobytes(), (n, m, k, shard)
+    select(ctx, "tiled", 0)
+
+
 @pytest.mark.parametrize("kernel,variant", [("stream", 0), ("tiled", 0), ("tiled", 1)])
 @pytest.mark.parametrize("k", [2, 3, 4])
 def test_split_factor_shards(ctx, oracle, kernel, variant, k):
@@ -187,7 +209,7 @@ def test_staged_rectangles_union(ctx, oracle, variant, world, chunks):
         d_bits = torch.full((n, bits.shape[1]), 0x5A5A5A5A5A5A5A5A, dtype=torch.int64,
                             device="cuda:0")
         src = torch.from_numpy(bits.view(np.int64))
-        ops = GpuStagedOps(ctx, sm, bits.shape[1], d_bits, -0.08, 200000)
+        ops = GpuStagedOps(ctx, sm, bits.shape[1], d_bits, -0.08, 250000)
         ops.begin()
         (ra, rb), steps = staged_schedule(n, tile, world, rank, chunks)
         for (c0, c1), rect in steps:
@@ -222,8 +244,8 @@ def test_staged_api_errors(ctx, oracle):
         ctx.prepare_samples(off, bits.shape[1], d_bits, 0, 100)
     ctx.prepare_samples(sm, bits.shape[1], d_bits, 0, 200)
     with pytest.raises(cuking_amd.CukingError):
-        ctx.compute_king_rect(sm, bits.shape[1], (0, 100), (0, 200), 0.0, 10, res,
-                              idx[0:1], idx[1:2])
+        ctx.compute_king_rect(sm, bits.shape[1], d_bits, (0, 100), (0, 200), 0.0, 10,
+                              res, idx[0:1], idx[1:2])
 
 
 @pytest.mark.parametrize("kernel,variant", [("stream", 0), ("tiled", 0)])
