@@ -265,3 +265,35 @@ def test_cli_result_overflow(c0):
     assert ("Error: RESOURCE_EXHAUSTED: Could not store all results: try increasing "
             "the --max_results parameter.") in p.stderr              # :747-751
     assert not (c0["dir"] / "out_ovf" / "part-00000.snappy.parquet").exists()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra,k,shard", [([], 1, 0), (["--split_factor=2", "--shard_index=0"], 2, 0),
+                                           (["--split-factor", "2", "--shard-index", "1"], 2, 1)])
+def test_python_driver_matches_oracle(c0, oracle, extra, k, shard):
+    """`python -m cuking_amd.run` (the multi-GPU driver, here with one rank):
+    same files, same schema, same records as the C++ binary."""
+    import subprocess
+    import sys
+    out = c0["dir"] / f"out_py_{k}_{shard}"
+    p = subprocess.run([sys.executable, "-m", "cuking_amd.run", "--input-uri",
+                        str(c0["dir"] / "in"), "--output_uri", str(out),
+                        "--kin-threshold=0.05", "--num_reader_threads=8", *extra],
+                       capture_output=True, text=True, timeout=600,
+                       cwd=str(Path(__file__).resolve().parent.parent))
+    assert p.returncode == 0, p.stderr
+    exp = expected_table(oracle, c0["geno"], c0["ids"], 0.05, k, shard)
+    check_output(out / f"part-{shard:05d}.snappy.parquet", exp, c0["ids"])
+
+
+def test_python_driver_flag_errors(tmp_path):
+    import subprocess
+    import sys
+    root = str(Path(__file__).resolve().parent.parent)
+    for argv, msg in ((["--output-uri", "x"], "No input URI specified"),
+                      (["--input-uri", "x", "--output-uri", "y", "--split-factor", "2",
+                        "--shard-index", "3"], "Invalid shard index"),
+                      (["--input-uri", "gs://b/x", "--output-uri", "y"], "Unsupported URI")):
+        p = subprocess.run([sys.executable, "-m", "cuking_amd.run", *argv],
+                           capture_output=True, text=True, timeout=300, cwd=root)
+        assert p.returncode == 1 and f"Error: INVALID_ARGUMENT: {msg}" in p.stderr, p.stderr
