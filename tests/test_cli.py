@@ -71,6 +71,64 @@ def test_missing_inputs(tmp_path):
     assert p.returncode == 1 and "Failed to parse metadata JSON" in p.stderr  # :485-487
 
 
+def test_metadata_json_variants(tmp_path, oracle):
+    """metadata.json as other writers may produce it: extra members, nesting,
+    escapes, \\u sequences, whitespace, any member order."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    d = tmp_path / "in"
+    d.mkdir()
+    ids = ["a\"b", "tab\there", "é", "\U0001F9EC", "plain"]
+    text = ('{ "extra": {"nested": [1, 2.5e3, true, null, {"x": "}"}]},\n'
+            '  "samples" : ["a\\"b", "tab\\there", "\\u00e9", "\\ud83e\\uddec", "plain"],\n'
+            '  "num_sites":70 , "z": -1.5 }')
+    assert json.loads(text)["samples"] == ids
+    (d / "metadata.json").write_text(text)
+    pq.write_table(pa.table({"row_idx": pa.array([69, 0], pa.int64()),
+                             "col_idx": pa.array([4, 1], pa.int64()),
+                             "n_alt_alleles": pa.array([2, 1], pa.int32())}), d / "t.parquet")
+    got = dump_bits(d, tmp_path, 5, cuking_amd.words_per_sample(70))
+    geno = np.full((5, 70), -1, dtype=np.int8)
+    geno[4, 69], geno[1, 0] = 2, 1
+    assert np.array_equal(got, oracle.bitset_from_genotypes(geno))
+    for bad in ('{"samples": ["a"]}', '{"num_sites": 3}', '{"num_sites": -1, "samples": []}',
+                '{"num_sites": 1.5, "samples": []}', '{"num_sites": 3, "samples": [1]}',
+                '{"num_sites": 3, "samples": ["a"]} x', '[]', ''):
+        (d / "metadata.json").write_text(bad)
+        p = run_cli("--input_uri", d, "--output_uri", tmp_path / "o", "--dump_bitset",
+                    tmp_path / "x.bin")
+        assert p.returncode == 1 and "metadata" in p.stderr, (bad, p.stderr)
+
+
+def test_host_code_under_asan_ubsan(tmp_path, oracle):
+    """The C++ host (flags, JSON, Parquet decode, pack driver) rebuilt with
+    AddressSanitizer + UBSan and run through the no-GPU --dump_bitset path."""
+    from cuking_amd import build as b
+    inc, libdir, libs = b.arrow_flags()
+    exe = tmp_path / "cuking_asan"
+    cmd = ["g++", "-O1", "-g", "-std=c++20", "-fsanitize=address,undefined",
+           "-fno-sanitize-recover=undefined", "-pthread", f"-I{b.INCLUDE}", f"-I{b.HOST}",
+           f"-isystem{inc}", *map(str, sorted(b.HOST.glob("*.cc"))), "-o", str(exe),
+           f"-L{b.PKG}", "-l:libcuking_amd.so", f"-L{libdir}", *libs,
+           f"-Wl,-rpath,{libdir}", f"-Wl,-rpath,{b.PKG}", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True)
+    rng = np.random.default_rng(9)
+    geno = random_genotypes(rng, 23, 300, missing=0.2)
+    write_input_tables(tmp_path / "in", geno, num_files=3, nullable=True, spark_layout=True)
+    dump = tmp_path / "bits.bin"
+    env = dict(**__import__("os").environ, ASAN_OPTIONS="detect_leaks=0")
+    p = subprocess.run([str(exe), "--input_uri", str(tmp_path / "in"), "--output_uri",
+                        str(tmp_path / "o"), "--dump_bitset", str(dump),
+                        "--num_reader_threads=3"], capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    got = np.fromfile(dump, dtype=np.uint64).reshape(23, -1)
+    assert np.array_equal(got, oracle.bitset_from_genotypes(geno))
+    p = subprocess.run([str(exe), "--input_uri", str(tmp_path / "none"), "--output_uri", "x",
+                        "--dump_bitset", str(dump)], capture_output=True, text=True, env=env)
+    assert p.returncode == 1 and "ERROR: AddressSanitizer" not in p.stderr
+
+
 # ------------------------------------------------- decode + pack (CPU) ----
 def dump_bits(in_dir, tmp_path, n_stored, wps, *extra):
     dump = tmp_path / "bits.bin"
