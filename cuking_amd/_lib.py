@@ -63,6 +63,8 @@ SIGNATURES = {
     "cuking_copy_to_device": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "cuking_copy_to_host": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "cuking_stream_synchronize": (_int, [_vp, _vp]),
+    "cuking_stream_create": (_int, [_vp, C.POINTER(_vp)]),
+    "cuking_stream_destroy": (_int, [_vp, _vp]),
     "cuking_host_alloc": (_int, [_vp, _sz, C.POINTER(_vp)]),
     "cuking_host_free": (_int, [_vp, _vp]),
     "cuking_pack_device": (_int, [_vp, _SM, _u32, _vp, _vp, _vp, _vp, _sz,

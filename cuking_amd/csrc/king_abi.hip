@@ -561,6 +561,23 @@ cuking_status cuking_stream_synchronize(cuking_ctx *ctx, void *stream) {
   return CUKING_OK;
 }
 
+cuking_status cuking_stream_create(cuking_ctx *ctx, void **stream) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  if (stream == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null out pointer");
+  hipStream_t s = nullptr;
+  HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = s;
+  return CUKING_OK;
+}
+
+cuking_status cuking_stream_destroy(cuking_ctx *ctx, void *stream) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+  return CUKING_OK;
+}
+
 cuking_status cuking_host_alloc(cuking_ctx *ctx, size_t bytes, void **ptr) {
   cuking_status st = bind(ctx);
   if (st != CUKING_OK) return st;

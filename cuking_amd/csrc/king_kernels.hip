@@ -244,7 +244,7 @@ __global__ __launch_bounds__(TIT *TJT, MINW) void king_tiled_kernel(
     const uint4 *l_cols = lds + (buf * 2 + 1) * KC * TILE;
     // Partial unroll only: a full unroll lets the scheduler hoist every
     // k-step's ds_reads and spills hundreds of VGPRs.
-#pragma unroll(KU)
+#pragma unroll KU
     for (int kc = 0; kc < KC; ++kc) {
       uint4 ri[RI], cj[RJ];
       const int kr = (ABLATE & 1) ? 0 : kc;

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <iomanip>
 #include <iostream>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -146,6 +147,75 @@ struct DeviceBuffers {
   }
 };
 
+// --pack=device: one per reader thread.  Triples of a decoded table are copied
+// into page-locked staging (two buffers, alternating), sent to the GPU and
+// packed by pack_kernel on the thread's own stream, so the next table is being
+// decoded (and the next chunk staged) while the previous one is in flight.
+class DevicePacker {
+ public:
+  static constexpr size_t kChunkTriples = size_t(2) << 20;  // 40 MiB per buffer
+  static constexpr size_t kBytesPerTriple = 8 + 8 + 4;
+
+  explicit DevicePacker(cuking_ctx *ctx) : ctx_(ctx) {}
+  ~DevicePacker() {
+    if (stream_) cuking_stream_synchronize(ctx_, stream_);
+    for (int b = 0; b < 2; ++b) {
+      if (host_[b]) cuking_host_free(ctx_, host_[b]);
+      if (dev_[b]) cuking_device_free(ctx_, dev_[b]);
+    }
+    if (stream_) cuking_stream_destroy(ctx_, stream_);
+  }
+
+  // Returns "" or the ABI error message.
+  std::string Pack(const cuking_submatrix &sm, uint32_t words_per_sample,
+                   uint64_t *d_bits, const cuking_host::Triples &t,
+                   uint32_t *d_status) {
+    if (!stream_ && cuking_stream_create(ctx_, &stream_) != CUKING_OK)
+      return cuking_last_error();
+    const size_t n = t.row_idx.size();
+    for (size_t done = 0; done < n; done += kChunkTriples) {
+      const size_t m = std::min(kChunkTriples, n - done);
+      const int b = next_;
+      next_ ^= 1;
+      if (!host_[b]) {
+        if (cuking_host_alloc(ctx_, kChunkTriples * kBytesPerTriple, &host_[b]) != CUKING_OK ||
+            cuking_device_alloc(ctx_, kChunkTriples * kBytesPerTriple, &dev_[b]) != CUKING_OK)
+          return cuking_last_error();
+      } else if (cuking_stream_synchronize(ctx_, stream_) != CUKING_OK) {
+        // (the buffer's previous chunk must have left the staging area; the
+        //  stream is in order, so this also covers the other buffer)
+        return cuking_last_error();
+      }
+      char *h = static_cast<char *>(host_[b]);
+      memcpy(h, t.row_idx.data() + done, m * 8);
+      memcpy(h + m * 8, t.col_idx.data() + done, m * 8);
+      memcpy(h + m * 16, t.n_alt_alleles.data() + done, m * 4);
+      char *d = static_cast<char *>(dev_[b]);
+      if (cuking_copy_to_device(ctx_, d, h, m * kBytesPerTriple, stream_) != CUKING_OK ||
+          cuking_pack_device(ctx_, &sm, words_per_sample, d_bits,
+                             reinterpret_cast<int64_t *>(d),
+                             reinterpret_cast<int64_t *>(d + m * 8),
+                             reinterpret_cast<int32_t *>(d + m * 16), m, d_status,
+                             stream_) != CUKING_OK)
+        return cuking_last_error();
+    }
+    return "";
+  }
+
+  std::string Finish() {
+    if (stream_ && cuking_stream_synchronize(ctx_, stream_) != CUKING_OK)
+      return cuking_last_error();
+    return "";
+  }
+
+ private:
+  cuking_ctx *ctx_;
+  void *stream_ = nullptr;
+  void *host_[2] = {nullptr, nullptr};
+  void *dev_[2] = {nullptr, nullptr};
+  int next_ = 0;
+};
+
 Status Run(const Flags &flags) {
   {
     const std::string err = cuking_host::ValidateFlags(flags);
@@ -214,7 +284,8 @@ Status Run(const Flags &flags) {
 
   std::cout << "Processing Parquet tables..." << std::flush;
   std::atomic<size_t> num_processed(0), num_triples(0);
-  std::mutex device_mu;  // the context is single-threaded
+  std::mutex device_mu;
+  std::vector<std::unique_ptr<DevicePacker>> packers;
   uint32_t *d_pack_status = nullptr;
   if (pack_on_device) {
     RETURN_IF_ERROR(FromAbi(cuking_device_alloc(buf.ctx, sizeof(uint32_t),
@@ -234,29 +305,17 @@ Status Run(const Flags &flags) {
             return std::string("FAILED_PRECONDITION\n") + cuking_last_error() + " in " +
                    input_files[f].first;
         } else if (n > 0) {
-          std::lock_guard<std::mutex> lock(device_mu);
-          void *d_row = nullptr, *d_col = nullptr, *d_alt = nullptr;
-          auto release = [&]() {
-            cuking_device_free(buf.ctx, d_row);
-            cuking_device_free(buf.ctx, d_col);
-            cuking_device_free(buf.ctx, d_alt);
-          };
-          bool ok =
-              cuking_device_alloc(buf.ctx, n * 8, &d_row) == CUKING_OK &&
-              cuking_device_alloc(buf.ctx, n * 8, &d_col) == CUKING_OK &&
-              cuking_device_alloc(buf.ctx, n * 4, &d_alt) == CUKING_OK &&
-              cuking_copy_to_device(buf.ctx, d_row, t.row_idx.data(), n * 8, nullptr) == CUKING_OK &&
-              cuking_copy_to_device(buf.ctx, d_col, t.col_idx.data(), n * 8, nullptr) == CUKING_OK &&
-              cuking_copy_to_device(buf.ctx, d_alt, t.n_alt_alleles.data(), n * 4, nullptr) == CUKING_OK &&
-              cuking_pack_device(buf.ctx, &sm, words_per_sample,
-                                 static_cast<uint64_t *>(buf.d_bits),
-                                 static_cast<int64_t *>(d_row), static_cast<int64_t *>(d_col),
-                                 static_cast<int32_t *>(d_alt), n, d_pack_status,
-                                 nullptr) == CUKING_OK &&
-              cuking_stream_synchronize(buf.ctx, nullptr) == CUKING_OK;
-          const std::string msg = ok ? "" : cuking_last_error();
-          release();
-          if (!ok) return "INTERNAL\n" + msg;
+          // One packer (stream + staging) per reader thread.
+          thread_local DevicePacker *packer = nullptr;
+          if (packer == nullptr) {
+            std::lock_guard<std::mutex> lock(device_mu);
+            packers.emplace_back(new DevicePacker(buf.ctx));
+            packer = packers.back().get();
+          }
+          const std::string msg =
+              packer->Pack(sm, words_per_sample, static_cast<uint64_t *>(buf.d_bits), t,
+                           d_pack_status);
+          if (!msg.empty()) return "INTERNAL\n" + msg;
         }
         num_triples += n;
         if ((++num_processed & 1023) == 0) std::cout << "." << std::flush;  // :705-708
@@ -278,6 +337,11 @@ Status Run(const Flags &flags) {
     return Status::Ok();
   }
   if (pack_on_device) {
+    for (auto &p : packers) {
+      const std::string msg = p->Finish();
+      if (!msg.empty()) return {"INTERNAL", msg};
+    }
+    packers.clear();
     uint32_t pack_status = 0;
     RETURN_IF_ERROR(FromAbi(cuking_copy_to_host(buf.ctx, &pack_status, d_pack_status,
                                                 sizeof(uint32_t), nullptr)));

@@ -117,6 +117,12 @@ cuking_status cuking_copy_to_device(cuking_ctx *ctx, void *d_dst,
 cuking_status cuking_copy_to_host(cuking_ctx *ctx, void *dst, const void *d_src,
                                   size_t bytes, void *stream);
 cuking_status cuking_stream_synchronize(cuking_ctx *ctx, void *stream);
+/* Extra streams for hosts without their own (e.g. one per Parquet reader
+ * thread).  The memory, copy, stream and cuking_pack_device entry points may
+ * be called from several host threads at once, each on its own stream; the
+ * compute / prepare / timing entry points need one caller at a time. */
+cuking_status cuking_stream_create(cuking_ctx *ctx, void **stream);
+cuking_status cuking_stream_destroy(cuking_ctx *ctx, void *stream);
 /* Page-locked host memory for staging buffers. */
 cuking_status cuking_host_alloc(cuking_ctx *ctx, size_t bytes, void **ptr);
 cuking_status cuking_host_free(cuking_ctx *ctx, void *ptr);
