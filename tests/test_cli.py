@@ -295,6 +295,20 @@ def test_c0_end_to_end(c0, oracle, extra):
 
 
 @pytest.mark.gpu
+def test_device_pack_multichunk_tables(c0, oracle):
+    """Tables larger than the packer's 2M-triple staging chunk (two files of
+    ~5M rows), two reader threads with their own streams."""
+    d = c0["dir"] / "in_two_files"
+    write_input_tables(d, c0["geno"], c0["ids"], num_files=2, compression="snappy",
+                       nullable=False, spark_layout=False)
+    out = c0["dir"] / "out_two_files"
+    run_cli("--input_uri", d, "--output_uri", out, "--kin_threshold=0.05", "--pack=device",
+            "--num_reader_threads=2", check=True)
+    exp = expected_table(oracle, c0["geno"], c0["ids"], 0.05)
+    check_output(out / "part-00000.snappy.parquet", exp, c0["ids"])
+
+
+@pytest.mark.gpu
 def test_c0_split_factor_shards(c0, oracle):
     """README.md:94-102: k = 3 => 6 shards, each its own part file."""
     out = c0["dir"] / "out_split"

@@ -72,6 +72,30 @@ def test_kat(ctx, oracle, kernel, variant):
     assert res["kin"].view(np.uint32)[0] == 0x3F000000
 
 
+@pytest.mark.parametrize("kernel,variant", KERNELS)
+def test_synth_golden_fixture(ctx, kernel, variant):
+    """Committed vectors (tests/golden/synth_96x700.json): device generator,
+    records unsharded and per shard -- no oracle involved at run time."""
+    import torch
+    from test_oracle import golden_records, load_synth_golden
+    select(ctx, kernel, variant)
+    g, bits = load_synth_golden()
+    n, m, thr = g["num_samples"], g["num_sites"], g["kin_threshold"]
+    as_t = lambda a: torch.tensor(a, dtype=torch.int32, device="cuda:0")
+    dev = ctx.synth_bitset(g["seed"], as_t(g["kind"]), as_t(g["pa"]), as_t(g["pb"]), 0, n, m)
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.cpu().numpy().view(np.uint64), bits)
+    got = ctx.run(cuking_amd.Submatrix(n), bits.shape[1], dev, thr)
+    assert got.tobytes() == golden_records(g["records"]).tobytes()
+    for shard, rows in enumerate(g["shards_split_factor_2"]):
+        sm = cuking_amd.Submatrix(n, 2, shard)
+        idx = list(range(sm.i_begin, sm.i_end))
+        if sm.i_begin != sm.j_begin:
+            idx += list(range(sm.j_begin, sm.j_end))
+        local = ctx.upload_bitset(np.ascontiguousarray(bits[idx]))
+        assert ctx.run(sm, bits.shape[1], local, thr).tobytes() == golden_records(rows).tobytes()
+
+
 SHAPES = [(2, 1), (3, 31), (5, 32), (7, 33), (16, 64), (33, 65), (63, 255),
           (64, 256), (65, 257), (130, 1000), (257, 3000), (100, 513)]
 

@@ -256,3 +256,31 @@ def test_sort_order(oracle):
     got = recs.copy()
     oracle.load().orc_sort(got.ctypes.data_as(C.c_void_p), got.size)
     assert got.tobytes() == exp.tobytes()
+
+
+def load_synth_golden():
+    g = json.loads((GOLDEN / "synth_96x700.json").read_text())
+    bits = np.frombuffer(bytes.fromhex("".join(g["bitset_hex"])), dtype=np.uint64).reshape(
+        g["num_samples"], g["bitset_words_per_sample"]).copy()
+    return g, bits
+
+
+def golden_records(rows):
+    from oracle.pyoracle import RESULT_DTYPE
+    out = np.zeros(len(rows), dtype=RESULT_DTYPE)
+    for k, (i, j, kin_bits, a, b, c) in enumerate(rows):
+        out[k] = (i, j, np.uint32(kin_bits).view(np.float32), a, b, c)
+    return out
+
+
+def test_synth_golden_fixture(oracle):
+    """tests/golden/synth_96x700.json (made by make_golden.py): generator,
+    pack layout and records are stable."""
+    g, bits = load_synth_golden()
+    again = oracle.synth_bitset(g["seed"], g["kind"], g["pa"], g["pb"], 0, g["num_samples"],
+                                g["num_sites"])
+    assert np.array_equal(again, bits)
+    res, ovf, _ = oracle.compute(oracle.submatrix(g["num_samples"]), bits, g["kin_threshold"])
+    assert res.tobytes() == golden_records(g["records"]).tobytes()
+    pairs = {(r[0], r[1]) for r in g["records"]}
+    assert {(3, 90), (10, 91), (11, 91), (91, 92), (10, 93)} <= pairs
