@@ -139,7 +139,7 @@ def main():
     import torch.distributed as dist
     import cuking_amd
     from cuking_amd.dist import (GpuStagedOps, all_pairs_king,
-                                 all_pairs_king_staged, row_partition,
+                                 all_pairs_king_staged, rank_tile_share,
                                  tile_partition)
     from cuking_amd.synth import cohort_to_device, plan_cohort
 
@@ -268,9 +268,7 @@ def main():
             # the sum over its launches (rectangles on two streams may overlap,
             # so this is an upper bound on the time the pair kernel was busy)
             if staged:
-                t_rows = (n + tile - 1) // tile
-                a, b = row_partition(t_rows, world)[0]
-                share = sum(t_rows - r for r in range(a, b)) / (t_rows * (t_rows + 1) / 2)
+                share = rank_tile_share((n + tile - 1) // tile, world, 0)
             else:
                 share = (my_tiles[1] - my_tiles[0]) / max(num_tiles, 1)
             launch_pairs, launches = pairs * share, args.steps

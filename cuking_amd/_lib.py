@@ -84,7 +84,8 @@ SIGNATURES = {
                                          _u32, _vp, _vp, _vp, _vp]),
     "cuking_prepare_samples": (_int, [_vp, _SM, _u32, _vp, _u32, _u32, _vp]),
     "cuking_compute_king_rect": (_int, [_vp, _SM, _u32, _vp, _u32, _u32, _u32,
-                                        _u32, _f32, _u32, _vp, _vp, _vp, _vp]),
+                                        _u32, _u32, _f32, _u32, _vp, _vp, _vp,
+                                        _vp]),
     "cuking_compute_counts": (_int, [_vp, _SM, _u32, _vp, _vp, _vp]),
     "cuking_sort_results": (None, [_vp, _sz]),
     "cuking_timing_enable": (_int, [_vp, _int]),

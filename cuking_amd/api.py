@@ -219,16 +219,19 @@ class KingContext:
                           bit_sets, rows, cols, kin_threshold: float,
                           max_results: int, results, result_index,
                           result_overflow, stream=None) -> None:
-        """Staged operator, step 2: pairs (i < j) of rows x cols (sample index
-        ranges) from the prepared layout; appends like compute_king."""
+        """Staged operator, step 2: pairs (i < j) of rows x cols from the
+        prepared layout; appends like compute_king.  rows = (begin, end) or
+        (begin, end, step): every tile row, or every (step / tile)-th one;
+        cols = (begin, end); sample indices."""
         self._check_bits(submatrix, words_per_sample, bit_sets)
         assert results.numel() * results.element_size() >= max_results * 24
+        step = rows[2] if len(rows) > 2 else 0
         check(self.lib.cuking_compute_king_rect(
             self.handle, C.byref(submatrix.c), words_per_sample,
-            bit_sets.data_ptr(), rows[0],
-            rows[1], cols[0], cols[1], kin_threshold, max_results,
-            results.data_ptr(), result_index.data_ptr(),
-            result_overflow.data_ptr(), _stream_handle(stream)))
+            bit_sets.data_ptr(), rows[0], rows[1], step, cols[0], cols[1],
+            kin_threshold, max_results, results.data_ptr(),
+            result_index.data_ptr(), result_overflow.data_ptr(),
+            _stream_handle(stream)))
 
     def compute_counts(self, submatrix: Submatrix, words_per_sample: int,
                        bit_sets, stream=None) -> np.ndarray:

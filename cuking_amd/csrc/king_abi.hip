@@ -279,6 +279,7 @@ cuking_status run_tiled(cuking_ctx *ctx, const cuking_submatrix &sm,
   a.result_overflow = d_result_overflow;
   a.dense_counts = d_counts;
   a.rect_rows = a.rect_row0 = a.rect_col0 = 0;
+  a.rect_row_stride = 1;
   a.bits = d_bit_sets;
   a.words_per_sample = words_per_sample;
 
@@ -757,9 +758,10 @@ cuking_status cuking_prepare_samples(cuking_ctx *ctx, const cuking_submatrix *sm
 
 cuking_status cuking_compute_king_rect(
     cuking_ctx *ctx, const cuking_submatrix *sm, uint32_t words_per_sample,
-    const uint64_t *d_bit_sets, uint32_t row_begin, uint32_t row_end, uint32_t col_begin, uint32_t col_end,
-    float kin_threshold, uint32_t max_results, cuking_result *d_results,
-    uint32_t *d_result_index, uint32_t *d_result_overflow, void *stream) {
+    const uint64_t *d_bit_sets, uint32_t row_begin, uint32_t row_end,
+    uint32_t row_step, uint32_t col_begin, uint32_t col_end, float kin_threshold,
+    uint32_t max_results, cuking_result *d_results, uint32_t *d_result_index,
+    uint32_t *d_result_overflow, void *stream) {
   cuking_status st = bind(ctx);
   if (st != CUKING_OK) return st;
   st = check_compute_args(sm, words_per_sample, d_bit_sets);
@@ -782,6 +784,13 @@ cuking_status cuking_compute_king_rect(
   st = tile_span(*sm, v.tile, col_begin, col_end, "column", &c0, &c1);
   if (st != CUKING_OK) return st;
   if (r0 == r1 || c0 == c1) return CUKING_OK;
+  if (row_step == 0) row_step = v.tile;
+  if (row_step % v.tile != 0)
+    return fail(CUKING_ERR_INVALID_ARGUMENT,
+                "row_step %u is not a multiple of the %u-sample tile edge", row_step,
+                v.tile);
+  const uint32_t stride = row_step / v.tile;
+  const uint32_t n_rows = (r1 - r0 + stride - 1) / stride;
 
   TiledArgs a;
   a.planes = ctx->planes;
@@ -789,9 +798,10 @@ cuking_status cuking_compute_king_rect(
   a.tiles = tiles;
   a.band_prefix = ctx->band_prefix;  // unused in rectangle mode
   a.tile_begin = 0;
-  a.rect_rows = r1 - r0;
+  a.rect_rows = n_rows;
   a.rect_row0 = r0;
   a.rect_col0 = c0;
+  a.rect_row_stride = stride;
   a.i_begin = sm->i_begin;
   a.j_begin = sm->j_begin;
   a.kin_threshold = kin_threshold;
@@ -805,7 +815,7 @@ cuking_status cuking_compute_king_rect(
   EventPair *ev = nullptr;
   if (ctx->timing) HIP_TRY(ctx->king_timer.begin((hipStream_t)stream, &ev));
   HIP_TRY(launch_tiled(ctx->variant, use_full_counts(ctx, kin_threshold, false), a,
-                       (uint64_t)(r1 - r0) * (c1 - c0), (hipStream_t)stream));
+                       (uint64_t)n_rows * (c1 - c0), (hipStream_t)stream));
   if (ev) HIP_TRY(hipEventRecord(ev->stop, (hipStream_t)stream));
   return CUKING_OK;
 }

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(TIT *TJT, MINW) void king_tiled_kernel(
   const uint64_t t = a.tile_begin + blockIdx.x;
   uint32_t tr, tc;
   if (a.rect_rows != 0) {
-    tr = a.rect_row0 + (uint32_t)(t % a.rect_rows);
+    tr = a.rect_row0 + (uint32_t)(t % a.rect_rows) * a.rect_row_stride;
     tc = a.rect_col0 + (uint32_t)(t / a.rect_rows);
     // Below the diagonal of a diagonal block: nothing to do.  The whole
     // workgroup leaves here, before any barrier.

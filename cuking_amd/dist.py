@@ -22,13 +22,15 @@ Two forms of the sharded pass:
                            of the tile enumeration (simple; the broadcast is
                            exposed).
 ``all_pairs_king_staged``  the broadcast is cut into sample chunks sent in
-                           ascending order; rank r owns a band of rows (equal
-                           tile counts per band) and, as soon as chunk c has
-                           landed, converts it and launches the rectangle
-                           rows(r) x chunk c.  A pair (i < j) only needs chunk(j)
-                           and everything before it, so every rank computes
-                           while later chunks are still on the wire: the
-                           exchange hides behind the kernel.
+                           ascending order; the ranks share the tile rows
+                           round-robin (row r belongs to rank r mod W, so every
+                           rank has work from the first chunk on) and, as soon
+                           as chunk c has landed, a rank converts it and
+                           launches the rectangle (its rows that have arrived)
+                           x (chunk c).  A pair (i < j) only needs chunk(j) and
+                           everything before it, so every rank computes while
+                           later chunks are still on the wire: the exchange
+                           hides behind the kernel.
 """
 from __future__ import annotations
 
@@ -110,22 +112,6 @@ def all_pairs_king(compute_tiles: Callable, num_tiles: int, bit_sets,
 # ---------------------------------------------------------------------------
 # Staged (overlapped) form
 # ---------------------------------------------------------------------------
-def row_partition(num_tile_rows: int, world_size: int) -> List[Tuple[int, int]]:
-    """Bands of tile rows with (nearly) equal numbers of upper-triangle tiles:
-    tile row r holds num_tile_rows - r tiles (the diagonal tile included)."""
-    t = num_tile_rows
-    total = t * (t + 1) // 2
-    bounds, acc, row = [0], 0, 0
-    for r in range(1, world_size):
-        target = total * r // world_size
-        while row < t and acc + (t - row) <= target:
-            acc += t - row
-            row += 1
-        bounds.append(row)
-    bounds.append(t)
-    return [(bounds[k], bounds[k + 1]) for k in range(world_size)]
-
-
 def chunk_ranges(num_samples: int, tile: int, num_chunks: int) -> List[Tuple[int, int]]:
     """Ascending, tile-aligned sample chunks covering [0, num_samples)."""
     tiles = (num_samples + tile - 1) // tile
@@ -139,21 +125,29 @@ def chunk_ranges(num_samples: int, tile: int, num_chunks: int) -> List[Tuple[int
     return out
 
 
+def rank_tile_share(num_tile_rows: int, world: int, rank: int) -> float:
+    """Fraction of the upper-triangle tiles on rank `rank` when tile rows are
+    dealt round-robin (row r holds num_tile_rows - r tiles)."""
+    t = num_tile_rows
+    mine = sum(t - r for r in range(rank, t, world))
+    return mine / (t * (t + 1) / 2) if t else 0.0
+
+
 def staged_schedule(num_samples: int, tile: int, world: int, rank: int,
                     num_chunks: int):
-    """What rank ``rank`` does per broadcast chunk: ((row_begin, row_end),
-    [((chunk_begin, chunk_end), rect or None), ...]) with rect = (rows, cols)
-    sample ranges.  A pair (i < j) is evaluated with the chunk that holds j."""
-    tiles = (num_samples + tile - 1) // tile
-    tr0, tr1 = row_partition(tiles, world)[rank]
-    ra, rb = min(tr0 * tile, num_samples), min(tr1 * tile, num_samples)
+    """What rank ``rank`` does per broadcast chunk: [((chunk_begin, chunk_end),
+    rect or None), ...] with rect = ((row_begin, row_end, row_step), (col_begin,
+    col_end)) in samples: the rank's tile rows (rank, rank + world, ...) that lie
+    below chunk_end x the chunk's columns.  A pair (i < j) is evaluated with the
+    chunk that holds j, by the rank that owns i's tile row."""
     steps = []
+    first_row = rank * tile
     for c0, c1 in chunk_ranges(num_samples, tile, num_chunks):
-        if c1 <= ra or ra == rb:
+        if first_row >= c1:
             steps.append(((c0, c1), None))
         else:
-            steps.append(((c0, c1), ((ra, min(rb, c1)), (max(c0, ra), c1))))
-    return (ra, rb), steps
+            steps.append(((c0, c1), ((first_row, c1, world * tile), (c0, c1))))
+    return steps
 
 
 def all_pairs_king_staged(ops, num_samples: int, tile: int, bit_sets,
@@ -164,14 +158,14 @@ def all_pairs_king_staged(ops, num_samples: int, tile: int, bit_sets,
     ``bit_sets`` is the [num_samples, words_per_sample] tensor (valid on
     ``src``, receive buffer elsewhere).  ``ops`` supplies the per-rank device
     work (see ``GpuStagedOps``): ``begin()``, ``prepare(s0, s1)``,
-    ``compute_rect((r0, r1), (c0, c1))`` and ``finish() -> (records, count,
-    overflow)``.  Returns (sorted records on dst else None, (row_begin, row_end))."""
+    ``compute_rect((r0, r1, step), (c0, c1))`` and ``finish() -> (records, count,
+    overflow)``.  Returns (sorted records on dst else None, the rank's schedule)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     else:
         rank, world = 0, 1
-    (ra, rb), steps = staged_schedule(num_samples, tile, world, rank, num_chunks)
+    steps = staged_schedule(num_samples, tile, world, rank, num_chunks)
 
     ops.begin()
     # All chunk broadcasts are enqueued up front; they complete in order.
@@ -193,8 +187,8 @@ def all_pairs_king_staged(ops, num_samples: int, tile: int, bit_sets,
                 "Could not store all results: try increasing the --max_results "
                 "parameter.")
         recs = np.ascontiguousarray(local[:count].cpu().numpy()).view(np.uint32)
-        return sort_results(recs.reshape(-1).view(KING_RESULT_DTYPE).copy()), (ra, rb)
-    return gather_results(local, count, overflow, dst=dst, group=group), (ra, rb)
+        return sort_results(recs.reshape(-1).view(KING_RESULT_DTYPE).copy()), steps
+    return gather_results(local, count, overflow, dst=dst, group=group), steps
 
 
 class GpuStagedOps:

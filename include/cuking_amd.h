@@ -207,8 +207,11 @@ cuking_status cuking_compute_king_tiles(
  * cuking_prepare_samples() converts samples [sample_begin, sample_end) (global
  * indices, tile aligned except at the block end) into the context's kernel
  * layout; cuking_compute_king_rect() then evaluates the pairs (i < j) of rows
- * [row_begin, row_end) x columns [col_begin, col_end) whose samples have all
- * been prepared.  Rectangles that tile the upper triangle reproduce
+ * x columns [col_begin, col_end) whose samples have all been prepared, where
+ * the rows are the tile rows starting at row_begin, row_begin + row_step, ...
+ * below row_end (row_step = 0 or the tile edge: every row of the range; a
+ * multiple of the tile edge: every n-th tile row, which is how the GPUs of a
+ * node share the rows round-robin).  Rectangles that tile the upper triangle reproduce
  * cuking_compute_king() exactly.  Both are asynchronous on `stream`; kernels
  * of different rectangles may run concurrently on different streams (they only
  * read the prepared layout and append atomically). */
@@ -219,9 +222,10 @@ cuking_status cuking_prepare_samples(cuking_ctx *ctx, const cuking_submatrix *sm
                                      void *stream);
 cuking_status cuking_compute_king_rect(
     cuking_ctx *ctx, const cuking_submatrix *sm, uint32_t words_per_sample,
-    const uint64_t *d_bit_sets, uint32_t row_begin, uint32_t row_end, uint32_t col_begin, uint32_t col_end,
-    float kin_threshold, uint32_t max_results, cuking_result *d_results,
-    uint32_t *d_result_index, uint32_t *d_result_overflow, void *stream);
+    const uint64_t *d_bit_sets, uint32_t row_begin, uint32_t row_end,
+    uint32_t row_step, uint32_t col_begin, uint32_t col_end, float kin_threshold,
+    uint32_t max_results, cuking_result *d_results, uint32_t *d_result_index,
+    uint32_t *d_result_overflow, void *stream);
 
 /* Diagnostic: the six sums of every pair, no threshold.  d_counts holds
  * NumRows x NumCols records, pair (i, j) at [(i - i_begin) * NumCols +

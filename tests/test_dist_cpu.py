@@ -43,20 +43,19 @@ class OracleStagedOps:
         self.prepared[s0:s1] = True
 
     def compute_rect(self, rows, cols):
-        (r0, r1), (c0, c1) = rows, cols
-        assert self.prepared[r0:r1].all() and self.prepared[c0:c1].all()
-        # split into diagonal part and the part strictly right of it
-        if c0 < r1:   # overlaps the rows: [r0,r1) x [c0,c1) with i<j
-            lo, hi = min(r0, c0), max(r1, c1)
+        (r0, r1, step), (c0, c1) = rows, cols
+        tile = 64
+        assert step % tile == 0 and r0 % tile == 0
+        assert self.prepared[c0:c1].all()
+        for a in range(r0, r1, step):          # the rank's tile rows
+            b = min(a + tile, self.bits.shape[0])
+            assert self.prepared[a:b].all()
+            lo, hi = min(a, c0), max(b, c1)
             osm = self.o.Submatrix(lo, hi, lo, hi)
             r, _, _ = self.o.compute(osm, np.ascontiguousarray(self.snapshot[lo:hi]), self.thr)
-            keep = ((r["sample_i"] >= r0) & (r["sample_i"] < r1) &
+            keep = ((r["sample_i"] >= a) & (r["sample_i"] < b) &
                     (r["sample_j"] >= c0) & (r["sample_j"] < c1))
             self.recs.append(r[keep])
-        else:
-            osm = self.o.Submatrix(r0, r1, c0, c1)
-            sub = np.concatenate([self.snapshot[r0:r1], self.snapshot[c0:c1]])
-            self.recs.append(self.o.compute(osm, np.ascontiguousarray(sub), self.thr)[0])
 
     def finish(self):
         recs = (np.concatenate(self.recs) if self.recs
@@ -87,7 +86,7 @@ def _staged_worker(rank, world, port, n, m, thr, chunks, out_path):
         geno[n // 3] = geno[n // 2]
         bits.copy_(torch.from_numpy(pyoracle.bitset_from_genotypes(geno).view(np.int64)))
     ops = OracleStagedOps(pyoracle, bits, thr, 100000)
-    merged, (ra, rb) = all_pairs_king_staged(ops, n, 64, bits, num_chunks=chunks)
+    merged, _ = all_pairs_king_staged(ops, n, 64, bits, num_chunks=chunks)
     if rank == 0:
         host = np.ascontiguousarray(bits.numpy().view(np.uint64))
         exp, _, _ = pyoracle.compute(pyoracle.submatrix(n), host, thr)
@@ -196,23 +195,23 @@ def test_staged_overlapped_pass_equals_single_pass(tmp_path, world, chunks):
                                                  (130, 64, 2, 8), (64, 64, 2, 3),
                                                  (2000, 128, 4, 5), (65, 64, 8, 8)])
 def test_staged_schedule_covers_every_pair_once(n, tile, world, chunks):
-    from cuking_amd.dist import row_partition, staged_schedule
+    from cuking_amd.dist import rank_tile_share, staged_schedule
     cover = np.zeros((n, n), dtype=np.int32)
+    t = (n + tile - 1) // tile
     for r in range(world):
-        (ra, rb), steps = staged_schedule(n, tile, world, r, chunks)
-        for (c0, c1), rect in steps:
+        for (c0, c1), rect in staged_schedule(n, tile, world, r, chunks):
             if rect is None:
                 continue
-            (r0, r1), (q0, q1) = rect
-            assert ra <= r0 and r1 <= rb
-            assert r1 <= c1 and q1 <= c1      # only samples that have arrived
-            assert r0 % tile == 0 and q0 % tile == 0
-            I, J = np.meshgrid(np.arange(r0, r1), np.arange(q0, q1), indexing="ij")
-            cover[I[I < J], J[I < J]] += 1
+            (r0, r1, step), (q0, q1) = rect
+            assert (q0, q1) == (c0, c1) and r1 <= c1     # only samples that have arrived
+            assert r0 == r * tile and step == world * tile
+            for a in range(r0, r1, step):
+                b = min(a + tile, n)
+                I, J = np.meshgrid(np.arange(a, b), np.arange(q0, q1), indexing="ij")
+                cover[I[I < J], J[I < J]] += 1
     assert np.all(cover[np.triu_indices(n, 1)] == 1)
     assert cover.sum() == n * (n - 1) // 2
-    t = (n + tile - 1) // tile
-    sizes = [sum(t - r for r in range(a, b)) for a, b in row_partition(t, world)]
-    assert sum(sizes) == t * (t + 1) // 2
-    if t >= 8 * world:
-        assert max(sizes) <= 1.15 * (sum(sizes) / world)
+    shares = [rank_tile_share(t, world, r) for r in range(world)]
+    assert abs(sum(shares) - 1.0) < 1e-12
+    if t >= 16 * world:
+        assert max(shares) <= 1.1 / world

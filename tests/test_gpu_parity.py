@@ -235,8 +235,7 @@ def test_staged_rectangles_union(ctx, oracle, variant, world, chunks):
         src = torch.from_numpy(bits.view(np.int64))
         ops = GpuStagedOps(ctx, sm, bits.shape[1], d_bits, -0.08, 250000)
         ops.begin()
-        (ra, rb), steps = staged_schedule(n, tile, world, rank, chunks)
-        for (c0, c1), rect in steps:
+        for (c0, c1), rect in staged_schedule(n, tile, world, rank, chunks):
             d_bits[c0:c1].copy_(src[c0:c1])          # "chunk arrives"
             if rect is None:
                 continue
