@@ -500,6 +500,11 @@ cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
     ctx->band_rows = (uint32_t)value;
     return CUKING_OK;
   }
+  if (strcmp(key, "max_launch_blocks") == 0) {  // test hook, process-wide
+    if (value < 0) return fail(CUKING_ERR_INVALID_ARGUMENT, "negative block cap");
+    set_max_blocks_per_launch((uint64_t)value);
+    return CUKING_OK;
+  }
   if (strcmp(key, "counts_mode") == 0) {
     if (value < -1 || value > 1)
       return fail(CUKING_ERR_INVALID_ARGUMENT, "counts_mode outside [-1, 1]");

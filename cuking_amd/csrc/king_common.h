@@ -134,6 +134,9 @@ hipError_t launch_tiled(int variant, bool full, const TiledArgs &args,
 
 // Converts plane-sample tiles [s_tile_begin, s_tile_end) (units of 64 plane
 // samples) of the block.
+// Test hook: cap the workgroups per launch (0 = hardware limit only).
+void set_max_blocks_per_launch(uint64_t blocks);
+
 hipError_t launch_prepare_planes(const uint64_t *d_bit_sets,
                                  uint32_t words_per_sample,
                                  const PlaneGeometry &geo, uint4 *d_planes,

@@ -351,12 +351,13 @@ __global__ __launch_bounds__(256) void king_stream_kernel(
     const cuking_submatrix sm, const uint32_t words_per_sample,
     const uint64_t *__restrict__ bits, const float kin_threshold,
     const uint32_t max_results, cuking_result *results, uint32_t *result_index,
-    uint32_t *result_overflow, cuking_counts *dense_counts) {
+    uint32_t *result_overflow, cuking_counts *dense_counts,
+    const uint64_t block_offset) {
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = threadIdx.x >> 6;
   const uint32_t num_cols = sm_num_cols(sm);
   const uint32_t col_groups = (num_cols + 3) / 4;
-  const uint64_t b = blockIdx.x;
+  const uint64_t b = block_offset + blockIdx.x;
   const uint32_t li = (uint32_t)(b / col_groups);
   const uint32_t lj = (uint32_t)(b % col_groups) * 4 + wave;
   const uint32_t i = sm.i_begin + li, j = sm.j_begin + lj;
@@ -455,6 +456,13 @@ __global__ __launch_bounds__(256) void pack_kernel(
   if (bad) atomicOr(status, bad);
 }
 
+uint64_t g_max_blocks_override = 0;  // tests: force splitting at small sizes
+
+uint64_t max_blocks_per_launch(uint32_t threads) {
+  const uint64_t hw = 0xFFFFFFFFull / threads;
+  return (g_max_blocks_override && g_max_blocks_override < hw) ? g_max_blocks_override : hw;
+}
+
 template <int TIT, int TJT, int RI, int RJ, int KC, int KU, int MINW, bool FULL,
           int ABLATE = 0>
 hipError_t launch_variant(const TiledArgs &args, uint64_t num_tiles,
@@ -468,11 +476,12 @@ hipError_t launch_variant(const TiledArgs &args, uint64_t num_tiles,
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  // Grid x is limited to 2^31 - 1 workgroups; split larger tile ranges.
+  // One launch may not exceed 2^32 - 1 threads in x (HIP truncates silently
+  // beyond that), so long tile ranges go out as several launches.
+  const uint64_t cap = max_blocks_per_launch(TIT * TJT);
   uint64_t done = 0;
   while (done < num_tiles) {
-    const uint64_t n = (num_tiles - done < (1ull << 30)) ? num_tiles - done
-                                                        : (1ull << 30);
+    const uint64_t n = (num_tiles - done < cap) ? num_tiles - done : cap;
     TiledArgs a = args;
     a.tile_begin = args.tile_begin + done;
     kernel<<<dim3((uint32_t)n), dim3(TIT * TJT), lds_bytes, stream>>>(a);
@@ -499,6 +508,8 @@ const TiledVariant kVariants[kNumTiledVariants] = {
 };
 
 }  // namespace
+
+void set_max_blocks_per_launch(uint64_t blocks) { g_max_blocks_override = blocks; }
 
 const TiledVariant &tiled_variant(int v) { return kVariants[v]; }
 
@@ -551,12 +562,16 @@ hipError_t launch_stream(const cuking_submatrix &sm, uint32_t words_per_sample,
   const uint64_t rows = sm_num_rows(sm);
   const uint64_t col_groups = ((uint64_t)sm_num_cols(sm) + 3) / 4;
   const uint64_t blocks = rows * col_groups;
-  if (blocks == 0) return hipSuccess;
-  if (blocks >= (1ull << 31)) return hipErrorInvalidValue;
-  king_stream_kernel<<<dim3((uint32_t)blocks), dim3(256), 0, stream>>>(
-      sm, words_per_sample, d_bit_sets, kin_threshold, max_results, d_results,
-      d_result_index, d_result_overflow, d_dense_counts);
-  return hipGetLastError();
+  const uint64_t cap = max_blocks_per_launch(256);
+  for (uint64_t done = 0; done < blocks; done += cap) {
+    const uint64_t n = blocks - done < cap ? blocks - done : cap;
+    king_stream_kernel<<<dim3((uint32_t)n), dim3(256), 0, stream>>>(
+        sm, words_per_sample, d_bit_sets, kin_threshold, max_results, d_results,
+        d_result_index, d_result_overflow, d_dense_counts, done);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 hipError_t launch_pack(const cuking_submatrix &sm, uint32_t words_per_sample,

@@ -57,9 +57,10 @@ __global__ __launch_bounds__(256) void synth_kernel(
     const uint32_t *__restrict__ pa, const uint32_t *__restrict__ pb,
     const uint32_t sample_begin, const uint32_t sample_end,
     const uint32_t num_sites, const uint32_t words_per_sample,
-    uint64_t *__restrict__ bit_set) {
+    uint64_t *__restrict__ bit_set, const uint64_t block_offset) {
   const uint32_t plane = words_per_sample / 2;
-  const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t idx = block_offset * blockDim.x + (uint64_t)blockIdx.x * blockDim.x +
+                       threadIdx.x;
   const uint64_t total = (uint64_t)(sample_end - sample_begin) * plane;
   if (idx >= total) return;
   const uint32_t row = (uint32_t)(idx / plane);
@@ -111,11 +112,16 @@ hipError_t launch_synth(uint64_t seed, const uint32_t *d_kind,
       (uint64_t)(sample_end - sample_begin) * (words_per_sample / 2);
   if (total == 0) return hipSuccess;
   const uint64_t blocks = (total + 255) / 256;
-  if (blocks >= (1ull << 31)) return hipErrorInvalidValue;
-  synth_kernel<<<dim3((uint32_t)blocks), dim3(256), 0, stream>>>(
-      seed, d_kind, d_pa, d_pb, sample_begin, sample_end, num_sites,
-      words_per_sample, d_bit_set);
-  return hipGetLastError();
+  const uint64_t cap = 0xFFFFFFFFull / 256;  // < 2^32 threads per launch
+  for (uint64_t done = 0; done < blocks; done += cap) {
+    const uint64_t n = blocks - done < cap ? blocks - done : cap;
+    synth_kernel<<<dim3((uint32_t)n), dim3(256), 0, stream>>>(
+        seed, d_kind, d_pa, d_pb, sample_begin, sample_end, num_sites,
+        words_per_sample, d_bit_set, done);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 }  // namespace cuking

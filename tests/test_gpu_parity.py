@@ -302,6 +302,28 @@ def test_result_overflow(ctx, oracle, kernel, variant):
     assert got.tobytes() == exp.tobytes()
 
 
+@pytest.mark.parametrize("kernel,variant", [("stream", 0), ("tiled", 0), ("tiled", 2)])
+def test_long_ranges_are_split_into_several_launches(ctx, oracle, kernel, variant):
+    """One launch may not exceed 2^32 - 1 threads (beyond that HIP truncates
+    silently): long tile / pair ranges go out as several launches.  The cap is
+    lowered here so that a small block needs many launches."""
+    select(ctx, kernel, variant)
+    rng = np.random.default_rng(77)
+    n, m = 500, 300
+    geno = random_genotypes(rng, n, m)
+    geno[499] = geno[7]
+    bits = oracle.bitset_from_genotypes(geno)
+    exp, _, _ = oracle.compute(oracle.submatrix(n), bits, 0.1)
+    d_bits = ctx.upload_bitset(bits)
+    try:
+        for cap in (1, 7, 1000):
+            ctx.set_option("max_launch_blocks", cap)
+            got = ctx.run(cuking_amd.Submatrix(n), bits.shape[1], d_bits, 0.1)
+            assert got.tobytes() == exp.tobytes(), cap
+    finally:
+        ctx.set_option("max_launch_blocks", 0)
+
+
 def test_appending_calls_share_one_buffer(ctx, oracle):
     """result_index is not reset by the call (cuking.cu:721-722 leaves that to
     the caller), so shards can append into one buffer."""
@@ -487,7 +509,11 @@ def test_c1_kernels_and_variants_agree(ctx, c1):
     for variant in range(4):
         select(ctx, "tiled", variant)
         assert ctx.run(sm, bits.shape[1], bits, 0.05).tobytes() == base, variant
-    # the streaming kernel on the last 1500 samples (all relatives live there)
+    # the streaming kernel on the whole cohort: 10000 x 2500 workgroups of 256
+    # threads = 6.4e9 threads, i.e. more than one launch may hold
+    select(ctx, "stream", 0)
+    assert ctx.run(sm, bits.shape[1], bits, 0.05).tobytes() == base
+    # ... and on the last 1500 samples (all relatives live there)
     lo = n - 1500
     select(ctx, "stream", 0)
     sub = cuking_amd.Submatrix.from_ranges(lo, n, lo, n)
