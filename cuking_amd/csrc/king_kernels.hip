@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void prepare_planes_kernel(
 //     concordant_hom = hh - opp, shared = hi + hj - bh + hh.
 // ---------------------------------------------------------------------------
 template <int TIT, int TJT, int RI, int RJ, int KC, int KU, int MINW, bool FULL,
-          int ABLATE = 0>
+          int ABLATE = 0>  // ABLATE bit 2: column operands loaded one at a time
 __global__ __launch_bounds__(TIT *TJT, MINW) void king_tiled_kernel(
     const TiledArgs a) {
   constexpr int TILE = TIT * RI;
@@ -250,8 +250,10 @@ __global__ __launch_bounds__(TIT *TJT, MINW) void king_tiled_kernel(
       const int kr = (ABLATE & 1) ? 0 : kc;
 #pragma unroll
       for (int x = 0; x < RI; ++x) ri[x] = l_rows[kr * TILE + x * TIT + ti];
+      if (!(ABLATE & 4)) {
 #pragma unroll
-      for (int y = 0; y < RJ; ++y) cj[y] = l_cols[kr * TILE + y * TJT + tj];
+        for (int y = 0; y < RJ; ++y) cj[y] = l_cols[kr * TILE + y * TJT + tj];
+      }
       if (ABLATE & 1) {  // keep the logic ops from being hoisted
 #pragma unroll
         for (int x = 0; x < RI; ++x)
@@ -259,6 +261,24 @@ __global__ __launch_bounds__(TIT *TJT, MINW) void king_tiled_kernel(
 #pragma unroll
         for (int y = 0; y < RJ; ++y)
           asm volatile("" : "+v"(cj[y].x), "+v"(cj[y].y), "+v"(cj[y].z), "+v"(cj[y].w));
+      }
+      if (ABLATE & 4) {
+        // Register-lean order: one column operand live at a time.
+#pragma unroll
+        for (int y = 0; y < RJ; ++y) {
+          const uint4 c = l_cols[kr * TILE + y * TJT + tj];
+#pragma unroll
+          for (int x = 0; x < RI; ++x) {
+            const uint32_t hom_both = ri[x].z & c.z;
+            if (FULL) c_hh[x][y] += __builtin_popcount(hom_both);
+            c_opp[x][y] += __builtin_popcount(
+                __builtin_amdgcn_bitop3_b32(ri[x].y, c.y, hom_both, 0x28));
+            c_bh[x][y] += __builtin_popcount(ri[x].x & c.x);
+            c_hi[x][y] += __builtin_popcount(ri[x].x & c.w);
+            c_hj[x][y] += __builtin_popcount(ri[x].w & c.x);
+          }
+        }
+        continue;
       }
 #pragma unroll
       for (int x = 0; x < RI; ++x) {
@@ -531,7 +551,7 @@ hipError_t launch_tiled(int variant, bool full, const TiledArgs &args,
     case 6: return launch_variant<16, 16, 4, 4, 8, 2, 4, false, 3>(args, num_tiles, lds, stream);
     case 7: return launch_variant<16, 16, 4, 4, 8, 4, 4, false>(args, num_tiles, lds, stream);
     case 8: return launch_variant<16, 16, 4, 4, 8, 1, 4, false>(args, num_tiles, lds, stream);
-    case 9: return launch_variant<16, 16, 4, 4, 8, 2, 5, false>(args, num_tiles, lds, stream);
+    case 9: return launch_variant<16, 16, 4, 4, 8, 1, 5, false, 4>(args, num_tiles, lds, stream);
 #endif
     default: return hipErrorInvalidValue;
   }

@@ -322,6 +322,12 @@ def test_c0_split_factor_shards(c0, oracle):
         parts.append(exp)
     whole = expected_table(oracle, c0["geno"], c0["ids"], thr)
     assert sum(len(p) for p in parts) == len(whole)
+    from cuking_amd.merge import merge
+    assert merge(out, 3, merged=out / "all.parquet").num_rows == len(whole)
+    assert (out / "_SUCCESS").exists()
+    (out / "all.parquet").unlink()
+    with pytest.raises(FileNotFoundError):
+        merge(out, 4)
     t = read_results(out)
     assert t.num_rows == len(whole)
     got = sorted(zip(t.column("i").to_pylist(), t.column("j").to_pylist()))
