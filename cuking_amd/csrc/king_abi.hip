@@ -199,7 +199,9 @@ cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
 
   const size_t need = (size_t)geo.k_words * geo.s_stride * sizeof(uint4);
   if (need > ctx->planes_bytes) {
-    HIP_TRY(hipStreamSynchronize(stream));
+    // Kernels of earlier calls (possibly on other streams) may still read the
+    // old workspace: wait for the whole device before replacing it.
+    HIP_TRY(hipDeviceSynchronize());
     if (ctx->planes) HIP_TRY(hipFree(ctx->planes));
     ctx->planes = nullptr;
     ctx->planes_bytes = 0;
@@ -208,7 +210,7 @@ cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
   }
   const uint32_t nb = tiles.num_bands();
   if ((size_t)nb + 1 > ctx->band_prefix_entries) {
-    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipDeviceSynchronize());
     if (ctx->band_prefix) HIP_TRY(hipFree(ctx->band_prefix));
     ctx->band_prefix = nullptr;
     ctx->band_prefix_entries = 0;

@@ -540,3 +540,43 @@ def test_c1_split_factor_union(ctx, c1):
         parts.append(ctx.run(sm, wps, local.contiguous(), 0.05))
     merged = cuking_amd.sort_results(np.ascontiguousarray(np.concatenate(parts)))
     assert merged.tobytes() == c1["res"].tobytes()
+
+
+def test_out_of_memory_is_reported(ctx):
+    """cuking.cu:113-118 exits the process on allocation failure; here it is a
+    status the caller can handle."""
+    import ctypes as C
+    ptr = C.c_void_p()
+    st = ctx.lib.cuking_device_alloc(ctx.handle, 1 << 50, C.byref(ptr))
+    assert st == _lib.ERR_OUT_OF_MEMORY and not ptr.value
+    assert b"hipMalloc" in ctx.lib.cuking_last_error()
+    # the context is still usable afterwards
+    st = ctx.lib.cuking_device_alloc(ctx.handle, 1 << 20, C.byref(ptr))
+    assert st == 0 and ptr.value
+    assert ctx.lib.cuking_device_free(ctx.handle, ptr) == 0
+
+
+def test_streams_from_the_abi(ctx, oracle):
+    """Hosts without their own stream objects (the C++ binary) create them
+    through the ABI; work on such a stream is ordered and waitable."""
+    import ctypes as C
+    import torch
+    select(ctx, "tiled", 0)
+    stream = C.c_void_p()
+    assert ctx.lib.cuking_stream_create(ctx.handle, C.byref(stream)) == 0 and stream.value
+    geno = random_genotypes(np.random.default_rng(4), 130, 400)
+    bits = oracle.bitset_from_genotypes(geno)
+    d_bits = ctx.upload_bitset(bits)
+    results = torch.zeros((20000, 6), dtype=torch.int32, device="cuda:0")
+    idx = torch.zeros(2, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    sm = cuking_amd.Submatrix(130)
+    _lib.check(ctx.lib.cuking_compute_king(ctx.handle, C.byref(sm.c), bits.shape[1],
+                                           d_bits.data_ptr(), 0.02, 20000, results.data_ptr(),
+                                           idx[0:1].data_ptr(), idx[1:2].data_ptr(), stream))
+    host_idx = (C.c_uint32 * 2)()
+    _lib.check(ctx.lib.cuking_copy_to_host(ctx.handle, host_idx, idx.data_ptr(), 8, stream))
+    _lib.check(ctx.lib.cuking_stream_synchronize(ctx.handle, stream))
+    exp, _, _ = oracle.compute(oracle.submatrix(130), bits, 0.02)
+    assert host_idx[0] == len(exp) and host_idx[1] == 0
+    assert ctx.lib.cuking_stream_destroy(ctx.handle, stream) == 0
