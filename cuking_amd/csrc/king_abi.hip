@@ -36,6 +36,7 @@ cuking_status fail(cuking_status code, const char *fmt, ...) {
   do {                                                                     \
     const hipError_t _e = (expr);                                          \
     if (_e != hipSuccess) {                                                \
+      (void)hipGetLastError(); /* do not leave it sticky for other users */ \
       return fail(_e == hipErrorOutOfMemory ? CUKING_ERR_OUT_OF_MEMORY     \
                                             : CUKING_ERR_DEVICE,           \
                   "%s failed: %s", #expr, hipGetErrorString(_e));          \
