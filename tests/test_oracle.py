@@ -284,3 +284,33 @@ def test_synth_golden_fixture(oracle):
     assert res.tobytes() == golden_records(g["records"]).tobytes()
     pairs = {(r[0], r[1]) for r in g["records"]}
     assert {(3, 90), (10, 91), (11, 91), (91, 92), (10, 93)} <= pairs
+
+
+def test_formula_is_the_published_king_robust_estimator(oracle):
+    """The reference's expression (cuking.cu:291-294) is algebraically the
+    between-family KING-robust estimator of Manichaikul et al. 2010 (eq. 11),
+    which Hail documents for hl.king (linked at cuking.cu:231):
+        phi = (N_AaAa - 2 N_AAaa) / (2 min(N_Aa_i, N_Aa_j))
+              + 1/2 - (N_Aa_i + N_Aa_j) / (4 min(N_Aa_i, N_Aa_j))
+    Evaluated in float64 it agrees with the float32 two-rounding value to
+    within float32 resolution (SURVEY.md App. A.3: |delta| <= ~2^-23 at |kin|<=1;
+    bit-equality with a float64 implementation is not definable)."""
+    rng = np.random.default_rng(2010)
+    geno = random_genotypes(rng, 80, 4000, missing=0.02)
+    geno[79] = geno[0]
+    sm = oracle.submatrix(80)
+    _, _, c, kin = oracle.all_pairs(sm, oracle.bitset_from_genotypes(geno, sm))
+    hi, hj = c["het_i"].astype(np.float64), c["het_j"].astype(np.float64)
+    bh, opp = c["both_het"].astype(np.float64), c["opposing_hom"].astype(np.float64)
+    mn = np.minimum(hi, hj)
+    ok = mn > 0
+    paper = (bh - 2 * opp) / (2 * mn) + 0.5 - (hi + hj) / (4 * mn)
+    assert ok.sum() > 3000
+    delta = np.abs(paper[ok] - kin[ok].astype(np.float64))
+    assert delta.max() <= 2.0 ** -22
+    # the float32 value is the two-rounding evaluation fl(0.5 + fl(num/den)), not
+    # the rounding of the float64 value: near kin = 0 (quotient near -0.5) most
+    # pairs differ in the last bits, which is why parity is defined against the
+    # reference's float32 expression and only a tolerance against float64
+    direct = (0.5 + (2 * bh - 4 * opp - hi - hj)[ok] / (4 * mn[ok])).astype(np.float32)
+    assert np.mean(direct != kin[ok]) > 0.05
