@@ -284,6 +284,11 @@ Status Run(const Flags &flags) {
 
   std::cout << "Processing Parquet tables..." << std::flush;
   std::atomic<size_t> num_processed(0), num_triples(0);
+  std::atomic<uint64_t> decode_us(0), pack_us(0);  // summed over reader threads
+  auto now_us = []() {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(
+               std::chrono::steady_clock::now().time_since_epoch()).count();
+  };
   std::mutex device_mu;
   std::vector<std::unique_ptr<DevicePacker>> packers;
   uint32_t *d_pack_status = nullptr;
@@ -296,9 +301,12 @@ Status Run(const Flags &flags) {
   const std::string pack_error = cuking_host::ParallelFor(
       flags.num_reader_threads, 0, input_files.size(), [&](size_t f) -> std::string {
         cuking_host::Triples t;
+        const uint64_t t_begin = now_us();
         std::string err = cuking_host::ReadTriples(input_files[f].first, &t);
         if (!err.empty()) return "FAILED_PRECONDITION\n" + err;
         const size_t n = t.row_idx.size();
+        const uint64_t t_decoded = now_us();
+        decode_us += t_decoded - t_begin;
         if (!pack_on_device) {
           if (cuking_pack_host(&sm, words_per_sample, host_bits, t.row_idx.data(),
                                t.col_idx.data(), t.n_alt_alleles.data(), n) != CUKING_OK)
@@ -317,6 +325,7 @@ Status Run(const Flags &flags) {
                            d_pack_status);
           if (!msg.empty()) return "INTERNAL\n" + msg;
         }
+        pack_us += now_us() - t_decoded;
         num_triples += n;
         if ((++num_processed & 1023) == 0) std::cout << "." << std::flush;  // :705-708
         return "";
@@ -420,7 +429,10 @@ Status Run(const Flags &flags) {
   const uint64_t pairs = cuking_submatrix_num_pairs(&sm);
   const double rate = kernel_seconds > 0 ? pairs / kernel_seconds : 0;
   std::cout << "{\"pairs\": " << pairs << ", \"triples\": " << num_triples.load()
-            << ", \"results\": " << num_results << ", \"kernel_seconds\": "
+            << ", \"results\": " << num_results << ", \"decode_thread_seconds\": "
+            << std::setprecision(3) << decode_us.load() * 1e-6
+            << ", \"pack_thread_seconds\": " << pack_us.load() * 1e-6
+            << ", \"kernel_seconds\": "
             << std::setprecision(6) << kernel_seconds << ", \"pairs_per_second\": "
             << std::setprecision(1) << rate << ", \"algorithmic_GBps\": "
             << rate * cuking_bytes_per_pair(words_per_sample) / 1e9 << "}" << std::endl;

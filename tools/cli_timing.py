@@ -37,5 +37,6 @@ for pack in ("host", "device"):
         phases = re.findall(r"^(.*?)\.\.\.\.* ?\(([\d.]+)s\)", p.stdout, flags=re.M)
         print(f"pack={pack} threads={threads} rc={p.returncode} wall={wall:.2f}s  " +
               "; ".join(f"{a.strip()[:28]}={b}s" for a, b in phases), flush=True)
+        print("   ", p.stdout.strip().splitlines()[-1])
         if p.returncode:
             print(p.stderr[-500:])
