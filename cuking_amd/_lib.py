@@ -106,9 +106,17 @@ def load() -> C.CDLL:
     if _lib is not None:
         return _lib
     if not LIB_PATH.exists():
-        raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python -m cuking_amd.build` "
-            "(hipcc, gfx950).  cuking_amd has no CPU fallback.")
+        # A source-only checkout: build the HIP library in-tree (hipcc cross-
+        # compiles gfx950 without a GPU).  This is a build step, not a fallback:
+        # without hipcc there is nothing to run and the import fails.
+        try:
+            from . import build as _build
+            _build.build_library()
+        except Exception as e:  # noqa: BLE001
+            raise ImportError(
+                f"{LIB_PATH} is missing and could not be built ({e}): run "
+                "`python -m cuking_amd.build` (hipcc, gfx950).  cuking_amd has no "
+                "CPU fallback.") from e
     # torch ships its own libamdhip64.so (same SONAME as /opt/rocm's).  A
     # process must hold exactly one HIP runtime, so when torch is going to be
     # used for device memory it has to be loaded first; our library then binds

@@ -276,6 +276,30 @@ def check_output(path, exp, ids):
         assert np.array_equal(t.column(name).to_numpy().astype(np.uint32), exp[name])
 
 
+def test_c0_cpu_plumbing_and_oracle_vs_naive(c0, oracle, naive, tmp_path):
+    """BASELINE.json configs[0] without a GPU: the binary's Parquet decode + pack
+    of the 1k x 10k cohort (8 zstd files, OPTIONAL columns, Spark layout) gives
+    the oracle's bitset, and on it the bit-plane oracle equals the naive
+    per-genotype oracle for all 499,500 pairs (counts exact, kin bit-exact)."""
+    geno = c0["geno"]
+    n, m = geno.shape
+    got = dump_bits(c0["dir"] / "in", tmp_path, n, cuking_amd.words_per_sample(m))
+    bits = oracle.bitset_from_genotypes(geno)
+    assert np.array_equal(got, bits)
+    oi, oj, counts, kin = oracle.all_pairs(oracle.submatrix(n), got)
+    ni, nj, nc = naive.all_pairs_matmul(geno)
+    assert len(oi) == n * (n - 1) // 2
+    assert np.array_equal(oi, ni) and np.array_equal(oj, nj)
+    for k, name in enumerate(counts.dtype.names):
+        assert np.array_equal(counts[name].astype(np.int64), nc[:, k]), name
+    nk = naive.kin_f32(nc[:, 0], nc[:, 1], nc[:, 2], nc[:, 3])
+    assert np.array_equal(kin.view(np.uint32), nk.view(np.uint32))
+    res, ovf, _ = oracle.compute(oracle.submatrix(n), got, 0.05, threads=4)
+    assert ovf == 0 and res.tobytes() == naive.king(geno, 0.05).tobytes()
+    related = {(int(r["sample_i"]), int(r["sample_j"])) for r in res}
+    assert {(10, 900), (20, 901), (21, 901), (901, 902), (22, 903)} <= related
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("extra", [[], ["--kernel=stream"], ["--pack=device"]])
 def test_c0_end_to_end(c0, oracle, extra):
