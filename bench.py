@@ -39,13 +39,14 @@ NUM_SIMDS = 256 * 4
 # king_kernels.hip, per pair per 32 sites: lean form 5 logic + 4 v_bcnt (used
 # when kin_threshold > 0), full form 5 + 5.
 VALU_OPS_PER_PAIR_WORD = {"lean": 9, "full": 10}
-# Measured on MI355X with the kernel's exact k-step instruction stream, explicit
-# registers, no memory traffic, 4 waves/SIMD (tools/micro/king_step.hip,
-# profiles/r01_valu_microbench.txt): in a stream that mixes full-rate (v_and,
-# v_bitop3: 2.1-2.4 cycles alone) and half-rate (v_bcnt_u32_b32: 4.2) wave64
-# instructions EVERY instruction costs ~4.06 issue cycles, in any order tried.
-# 16 pairs per k-step: 584.7 cycles (9 ops) / 651.4 cycles (10 ops).
-VALU_FLOOR_CYCLES_PER_PAIR_WORD = {"lean": 584.7 / 16, "full": 651.4 / 16}
+# VALU issue floor, measured on MI355X (tools/micro/king_step.hip, valu_phase.hip;
+# profiles/r01_valu_microbench.txt), cycles per wave64 instruction per SIMD:
+# v_and 2.07, v_bitop3 2.37, v_bcnt_u32_b32 4.19 when each kind runs alone.  The
+# phased kernel (logic phase / popcount phase, waves of a workgroup paired per
+# SIMD) is priced against the SUM of its parts: 4 x 2.07 + 2.37 + n_bcnt x 4.19.
+# (Unsynchronised waves mixing the kinds cost ~4.06 per instruction: 36.5 / 40.7.)
+VALU_FLOOR_CYCLES_PER_PAIR_WORD = {"lean": 4 * 2.07 + 2.37 + 4 * 4.19,
+                                   "full": 4 * 2.07 + 2.37 + 5 * 4.19}
 
 
 def parse_args():

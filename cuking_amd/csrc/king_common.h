@@ -119,9 +119,9 @@ struct TiledVariant {
 };
 
 #ifdef CUKING_TUNING
-constexpr int kNumTiledVariants = 10;  // + timing-only experiments
+constexpr int kNumTiledVariants = 11;  // + timing-only experiments
 #else
-constexpr int kNumTiledVariants = 4;
+constexpr int kNumTiledVariants = 5;
 #endif
 const TiledVariant &tiled_variant(int v);
 // Enqueues tiles [args.tile_begin, args.tile_begin + num_tiles).

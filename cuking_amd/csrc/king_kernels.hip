@@ -158,8 +158,20 @@ __global__ __launch_bounds__(256) void prepare_planes_kernel(
 //     het_i = hi, het_j = hj, both_het = bh, opposing_hom = opp,
 //     concordant_hom = hh - opp, shared = hi + hj - bh + hh.
 // ---------------------------------------------------------------------------
+// PHASED: a workgroup with two waves per SIMD runs every k-step as a logic
+// phase (v_and / v_bitop3 into temporaries) followed by a popcount phase
+// (v_bcnt), with one s_barrier in front of each logic phase.  Measured on
+// gfx950 (tools/micro/valu_phase.hip, profiles/r01_valu_microbench.txt): a
+// wave issues at most one VALU instruction per 4 cycles; a full-rate
+// instruction leaves half of that slot to ANOTHER wave's full-rate
+// instruction, a half-rate v_bcnt takes all of it.  Unsynchronised waves mix
+// the two kinds and every instruction costs ~4 cycles; two waves of one
+// workgroup on the same SIMD that enter their logic phases together pair
+// their full-rate instructions up, and the stream costs the sum of its parts
+// (~3.05 cycles per instruction for this mix).  (PHASED 2 / 3: barrier
+// placements that measured slower, tuning builds only.)
 template <int TIT, int TJT, int RI, int RJ, int KC, int KU, int MINW, bool FULL,
-          int ABLATE = 0>  // ABLATE bit 2: column operands loaded one at a time
+          int ABLATE = 0, int PHASED = 0>  // ABLATE bit 2: one column operand at a time
 __global__ __launch_bounds__(TIT *TJT, MINW) void king_tiled_kernel(
     const TiledArgs a) {
   constexpr int TILE = TIT * RI;
@@ -242,6 +254,63 @@ __global__ __launch_bounds__(TIT *TJT, MINW) void king_tiled_kernel(
 
     const uint4 *l_rows = lds + (buf * 2 + 0) * KC * TILE;
     const uint4 *l_cols = lds + (buf * 2 + 1) * KC * TILE;
+    if (PHASED) {
+      // Software pipelined: the operands of k-step kc+1 are requested right
+      // after the logic phase of kc has consumed the previous ones, so they
+      // arrive during the popcount phase.
+      uint4 ri[RI], cj[RJ];
+#pragma unroll
+      for (int x = 0; x < RI; ++x) ri[x] = l_rows[x * TIT + ti];
+#pragma unroll
+      for (int y = 0; y < RJ; ++y) cj[y] = l_cols[y * TJT + tj];
+#pragma unroll KU
+      for (int kc = 0; kc < KC; ++kc) {
+        uint32_t v_opp[RI][RJ], v_bh[RI][RJ], v_hi[RI][RJ], v_hj[RI][RJ],
+            v_hh[RI][RJ];
+        // --- logic phase: full-rate instructions only ---
+#pragma unroll
+        for (int x = 0; x < RI; ++x) {
+#pragma unroll
+          for (int y = 0; y < RJ; ++y) {
+            const uint32_t hom_both = ri[x].z & cj[y].z;
+            v_hh[x][y] = hom_both;
+            v_opp[x][y] =
+                __builtin_amdgcn_bitop3_b32(ri[x].y, cj[y].y, hom_both, 0x28);
+            v_bh[x][y] = ri[x].x & cj[y].x;
+            v_hi[x][y] = ri[x].x & cj[y].w;
+            v_hj[x][y] = ri[x].w & cj[y].x;
+          }
+        }
+        if (kc + 1 < KC) {
+#pragma unroll
+          for (int x = 0; x < RI; ++x) ri[x] = l_rows[(kc + 1) * TILE + x * TIT + ti];
+#pragma unroll
+          for (int y = 0; y < RJ; ++y) cj[y] = l_cols[(kc + 1) * TILE + y * TJT + tj];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (PHASED >= 2) __builtin_amdgcn_s_barrier();  // tuning only: measured slower
+        __builtin_amdgcn_sched_barrier(0);
+        // --- popcount phase: half-rate instructions only.  Inline asm keeps
+        // the accumulate fused (v_bcnt d, s, d): left to itself the compiler
+        // re-associates two k-steps into bcnt + bcnt + v_add3. ---
+#pragma unroll
+        for (int x = 0; x < RI; ++x) {
+#pragma unroll
+          for (int y = 0; y < RJ; ++y) {
+            if (FULL)
+              asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(c_hh[x][y]) : "v"(v_hh[x][y]));
+            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(c_opp[x][y]) : "v"(v_opp[x][y]));
+            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(c_bh[x][y]) : "v"(v_bh[x][y]));
+            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(c_hi[x][y]) : "v"(v_hi[x][y]));
+            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(c_hj[x][y]) : "v"(v_hj[x][y]));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (PHASED != 3) __builtin_amdgcn_s_barrier();  // aligns the next logic phase
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      continue;
+    }
     // Partial unroll only: a full unroll lets the scheduler hoist every
     // k-step's ds_reads and spills hundreds of VGPRs.
 #pragma unroll KU
@@ -484,10 +553,10 @@ uint64_t max_blocks_per_launch(uint32_t threads) {
 }
 
 template <int TIT, int TJT, int RI, int RJ, int KC, int KU, int MINW, bool FULL,
-          int ABLATE = 0>
+          int ABLATE = 0, int PHASED = 0>
 hipError_t launch_variant(const TiledArgs &args, uint64_t num_tiles,
                           uint32_t lds_bytes, hipStream_t stream) {
-  auto kernel = king_tiled_kernel<TIT, TJT, RI, RJ, KC, KU, MINW, FULL, ABLATE>;
+  auto kernel = king_tiled_kernel<TIT, TJT, RI, RJ, KC, KU, MINW, FULL, ABLATE, PHASED>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(
@@ -513,19 +582,21 @@ hipError_t launch_variant(const TiledArgs &args, uint64_t num_tiles,
 }
 
 const TiledVariant kVariants[kNumTiledVariants] = {
+    {"t64_r4x2_k16_phased", 64, 16, 512, 2 * 2 * 16 * 64 * 16},
     {"t64_r4x4_k8_w4", 64, 8, 256, 2 * 2 * 8 * 64 * 16},
     {"t128_r8x4_k8_w2", 128, 8, 512, 2 * 2 * 8 * 128 * 16},
     {"t128_r4x4_k8_w4", 128, 8, 1024, 2 * 2 * 8 * 128 * 16},
     {"t64_r4x4_k16_w4", 64, 16, 256, 2 * 2 * 16 * 64 * 16},
 #ifdef CUKING_TUNING
-    {"ablate_noldsread", 64, 8, 256, 2 * 2 * 8 * 64 * 16},
-    {"ablate_nodma_nobarrier", 64, 8, 256, 2 * 2 * 8 * 64 * 16},
-    {"ablate_both", 64, 8, 256, 2 * 2 * 8 * 64 * 16},
-    {"t64_r4x4_k8_u4", 64, 8, 256, 2 * 2 * 8 * 64 * 16},
-    {"t64_r4x4_k8_u1", 64, 8, 256, 2 * 2 * 8 * 64 * 16},
-    {"t64_r4x4_k8_w5", 64, 8, 256, 2 * 2 * 8 * 64 * 16},
+    {"phased_both_barriers", 64, 16, 512, 2 * 2 * 16 * 64 * 16},
+    {"phased_bar_before_popcount_only", 64, 16, 512, 2 * 2 * 16 * 64 * 16},
+    {"phased_k8", 64, 8, 512, 2 * 2 * 8 * 64 * 16},
+    {"unphased_noldsread", 64, 8, 256, 2 * 2 * 8 * 64 * 16},
+    {"unphased_nodma_nobarrier", 64, 8, 256, 2 * 2 * 8 * 64 * 16},
+    {"unphased_w5", 64, 8, 256, 2 * 2 * 8 * 64 * 16},
 #endif
 };
+
 
 }  // namespace
 
@@ -540,22 +611,27 @@ hipError_t launch_tiled(int variant, bool full, const TiledArgs &args,
 #define CUKING_SHAPE(...)                                                      \
   (full ? launch_variant<__VA_ARGS__, true>(args, num_tiles, lds, stream)      \
         : launch_variant<__VA_ARGS__, false>(args, num_tiles, lds, stream))
+#define CUKING_PHASED(KC_, MODE_)                                              \
+  (full ? launch_variant<16, 32, 4, 2, KC_, KC_, 4, true, 0, MODE_>(args, num_tiles, lds, stream) \
+        : launch_variant<16, 32, 4, 2, KC_, KC_, 4, false, 0, MODE_>(args, num_tiles, lds, stream))
   switch (variant) {
-    case 0: return CUKING_SHAPE(16, 16, 4, 4, 8, 2, 4);
-    case 1: return CUKING_SHAPE(16, 32, 8, 4, 8, 2, 2);
-    case 2: return CUKING_SHAPE(32, 32, 4, 4, 8, 2, 4);
-    case 3: return CUKING_SHAPE(16, 16, 4, 4, 16, 2, 4);
+    case 0: return CUKING_PHASED(16, 1);
+    case 1: return CUKING_SHAPE(16, 16, 4, 4, 8, 2, 4);
+    case 2: return CUKING_SHAPE(16, 32, 8, 4, 8, 2, 2);
+    case 3: return CUKING_SHAPE(32, 32, 4, 4, 8, 2, 4);
+    case 4: return CUKING_SHAPE(16, 16, 4, 4, 16, 2, 4);
 #ifdef CUKING_TUNING
-    case 4: return launch_variant<16, 16, 4, 4, 8, 2, 4, false, 1>(args, num_tiles, lds, stream);
-    case 5: return launch_variant<16, 16, 4, 4, 8, 2, 4, false, 2>(args, num_tiles, lds, stream);
-    case 6: return launch_variant<16, 16, 4, 4, 8, 2, 4, false, 3>(args, num_tiles, lds, stream);
-    case 7: return launch_variant<16, 16, 4, 4, 8, 4, 4, false>(args, num_tiles, lds, stream);
-    case 8: return launch_variant<16, 16, 4, 4, 8, 1, 4, false>(args, num_tiles, lds, stream);
-    case 9: return launch_variant<16, 16, 4, 4, 8, 1, 5, false, 4>(args, num_tiles, lds, stream);
+    case 5: return CUKING_PHASED(16, 2);
+    case 6: return CUKING_PHASED(16, 3);
+    case 7: return CUKING_PHASED(8, 1);
+    case 8: return launch_variant<16, 16, 4, 4, 8, 2, 4, false, 1>(args, num_tiles, lds, stream);
+    case 9: return launch_variant<16, 16, 4, 4, 8, 2, 4, false, 2>(args, num_tiles, lds, stream);
+    case 10: return launch_variant<16, 16, 4, 4, 8, 1, 5, false, 4>(args, num_tiles, lds, stream);
 #endif
     default: return hipErrorInvalidValue;
   }
 #undef CUKING_SHAPE
+#undef CUKING_PHASED
 }
 
 hipError_t launch_prepare_planes(const uint64_t *d_bit_sets,

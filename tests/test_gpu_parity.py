@@ -18,7 +18,7 @@ from conftest import GOLDEN, random_genotypes
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = [("stream", 0)] + [("tiled", v) for v in range(4)]
+KERNELS = [("stream", 0)] + [("tiled", v) for v in range(5)]
 
 
 def select(ctx, kernel, variant, counts_mode=-1):
@@ -137,7 +137,7 @@ def test_thresholded_records_bit_exact(ctx, oracle, kernel, variant, thr):
     assert got.tobytes() == exp.tobytes()   # i, j, kin bits, ibs0/1/2
 
 
-@pytest.mark.parametrize("variant", range(4))
+@pytest.mark.parametrize("variant", range(5))
 @pytest.mark.parametrize("counts_mode", [0, 1])
 @pytest.mark.parametrize("thr", [-1e30, 0.0, 0.1])
 def test_lean_and_full_forms_agree_with_oracle(ctx, oracle, variant, counts_mode, thr):
@@ -187,7 +187,7 @@ def test_split_factor_shards(ctx, oracle, kernel, variant, k):
     assert merged.tobytes() == full.tobytes()
 
 
-@pytest.mark.parametrize("variant", range(4))
+@pytest.mark.parametrize("variant", range(5))
 def test_tile_ranges_union(ctx, oracle, variant):
     """Pair-space sharding for multi-GPU: disjoint tile ranges == whole block."""
     select(ctx, "tiled", variant)
@@ -210,7 +210,7 @@ def test_tile_ranges_union(ctx, oracle, variant):
         ctx.run(sm, bits.shape[1], d_bits, -0.05, tile_range=(0, tiles + 1))
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 4])
 @pytest.mark.parametrize("world,chunks", [(1, 1), (1, 4), (2, 3), (3, 8), (8, 5)])
 def test_staged_rectangles_union(ctx, oracle, variant, world, chunks):
     """The overlapped multi-GPU schedule (chunked arrival, row bands, rectangle
@@ -506,7 +506,7 @@ def test_c1_kernels_and_variants_agree(ctx, c1):
     n, m, bits = c1["n"], c1["m"], c1["bits"]
     sm = cuking_amd.Submatrix(n)
     base = c1["res"].tobytes()
-    for variant in range(4):
+    for variant in range(5):
         select(ctx, "tiled", variant)
         assert ctx.run(sm, bits.shape[1], bits, 0.05).tobytes() == base, variant
     # the streaming kernel on the whole cohort: 10000 x 2500 workgroups of 256
