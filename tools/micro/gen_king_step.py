@@ -125,5 +125,5 @@ int main() {
 for name, seq in orders.items():
     src.append(f'  if (run("{name}", k_{name}, d, {len(seq)})) return 1;')
 src.append('  return 0;\n}')
-open('/root/repo/tools/micro/king_step.hip', 'w').write("\n".join(src) + "\n")
+open(__import__('os').path.dirname(__import__('os').path.abspath(__file__)) + '/king_step.hip', 'w').write("\n".join(src) + "\n")
 print({k: len(v) for k, v in orders.items()})

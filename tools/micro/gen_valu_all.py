@@ -74,4 +74,4 @@ int main() {
 for name, cname, n in names:
     src.append(f'  if (run("{name}", k_{cname}, dclk, d, {n})) return 1;')
 src.append('  return 0;\n}')
-open('/root/repo/tools/micro/valu_all.hip', 'w').write("\n".join(src) + "\n")
+open(__import__('os').path.dirname(__import__('os').path.abspath(__file__)) + '/valu_all.hip', 'w').write("\n".join(src) + "\n")

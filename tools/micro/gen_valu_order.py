@@ -50,4 +50,4 @@ int main() {
 for name in variants:
     src.append(f'  if (run("{name}", k_{name}, d)) return 1;')
 src.append('  return 0;\n}')
-open('/root/repo/tools/micro/valu_order.hip', 'w').write("\n".join(src) + "\n")
+open(__import__('os').path.dirname(__import__('os').path.abspath(__file__)) + '/valu_order.hip', 'w').write("\n".join(src) + "\n")

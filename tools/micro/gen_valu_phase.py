@@ -57,4 +57,4 @@ for name, threads, na, nb in runs:
     for wpc in ({256: (2, 4), 512: (1, 2), 1024: (1,)}[threads]):
         src.append(f'  if (run("{name}", k_{name}, d, {threads}, {na}, {nb}, {wpc})) return 1;')
 src.append('  return 0;\n}')
-open('/root/repo/tools/micro/valu_phase.hip', 'w').write("\n".join(src).replace("{init}", init) + "\n")
+open(__import__('os').path.dirname(__import__('os').path.abspath(__file__)) + '/valu_phase.hip', 'w').write("\n".join(src).replace("{init}", init) + "\n")

@@ -52,4 +52,4 @@ for name, seq in variants.items():
     na = sum(1 for x in seq if x.startswith("v_and")); nb = len(seq) - na
     src.append(f'  if (run("{name}", k_{name}, d, {na}, {nb})) return 1;')
 src.append('  return 0;\n}')
-open('/root/repo/tools/micro/valu_ratio.hip', 'w').write("\n".join(src) + "\n")
+open(__import__('os').path.dirname(__import__('os').path.abspath(__file__)) + '/valu_ratio.hip', 'w').write("\n".join(src) + "\n")
