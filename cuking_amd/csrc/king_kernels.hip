@@ -3,7 +3,8 @@
 //   prepare_planes_kernel  reference bitset (cuking.cu:507-523) -> k-major
 //                          4-plane layout (king_common.h)
 //   king_tiled_kernel      the throughput kernel: LDS-staged, register-tiled
-//                          AND+popcount over all pairs of a tile
+//                          AND+popcount over all pairs of a tile, issued as
+//                          barrier-aligned logic / popcount phases
 //                          (replaces ComputeKingKernel, cuking.cu:191-314)
 //   king_stream_kernel     one pair per wavefront straight from the reference
 //                          layout, wave-level reductions (same contract)
@@ -140,14 +141,17 @@ __global__ __launch_bounds__(256) void prepare_planes_kernel(
 // king_tiled_kernel
 //
 // Workgroup = one TILE x TILE tile of sample pairs, TIT x TJT threads, each
-// owning an RI x RJ micro-tile (rows q*TIT + ti, columns q*TJT + tj) with five
-// u32 accumulators per pair.  K is streamed in chunks of KC 32-site words:
+// owning an RI x RJ micro-tile (rows q*TIT + ti, columns q*TJT + tj) with four
+// (lean form) or five (full form) u32 accumulators per pair.  The shipped
+// shape is 16 x 32 threads, 4 x 2 pairs per thread, phased (see PHASED below).
+// K is streamed in chunks of KC 32-site words:
 // every chunk is 2 * KC rows of TILE uint4 (row side and column side), copied
 // global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave
 // instruction, no VGPR staging) into a double buffer while the previous chunk
 // is consumed with ds_read_b128.
 //
-// Per pair and 32-site word, 10 VALU ops:
+// Per pair and 32-site word, 10 VALU ops (9 in the lean form, which skips hh
+// and recounts it only for emitted pairs):
 //     t    = Hom_i & Hom_j                       v_and
 //     hh  += popc(t)                             v_bcnt (accumulating)
 //     opp += popc((A_i ^ A_j) & t)               v_bitop3 + v_bcnt
