@@ -31,6 +31,11 @@ class Submatrix(C.Structure):
 
 def build(native: bool = False, out_dir: os.PathLike | None = None) -> Path:
     """Compiles the oracle with gcc (oracle/Makefile) and returns the .so path."""
+    if native and out_dir is None:
+        # -march=native code must never travel to another machine: build it in
+        # a scratch directory of the machine that runs it.
+        import tempfile
+        out_dir = tempfile.mkdtemp(prefix="king_oracle_native_")
     out = Path(out_dir) if out_dir else _HERE
     out.mkdir(parents=True, exist_ok=True)
     target = "native" if native else "all"
