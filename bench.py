@@ -293,7 +293,7 @@ def main():
         # word (at the nominal clock) against the measured floor for this mix.
         cyc = (king_ms * 1e-3 * NOMINAL_CLOCK_HZ * NUM_SIMDS * 64 /
                (launch_pairs * wps)) if king_ms > 0 else 0.0
-        form = "lean" if thr > 0 else "full"
+        form = "lean" if thr > 0 and thr * thr * 32 * wps >= 1.6 * 1.6 else "full"
         floor = VALU_FLOOR_CYCLES_PER_PAIR_WORD[form]
         roofline["valu"] = {
             "form": form,

@@ -121,13 +121,20 @@ int default_variant() {
   return 0;
 }
 
-// Which form of the tiled kernel: the lean one unless (nearly) every pair will
-// be emitted -- a threshold at or below zero passes about half of all
-// unrelated pairs -- or the caller forces one.
-bool use_full_counts(const cuking_ctx *ctx, float kin_threshold, bool dense) {
+// Which form of the tiled kernel.  The lean form saves one v_bcnt per pair and
+// word but recounts hom/hom sites for every EMITTED pair (measured at 100k
+// sites: +3 ms per 10^6 emitted pairs, against +6.6 ms for the full form at
+// 5x10^7 pairs; break-even near 4 % of the pairs emitted).  For unrelated
+// samples kinship scatters around 0 with a spread ~ 1/sqrt(sites) (at 100k
+// sites 2 % of the pairs exceed 0.005), so the automatic choice is lean iff
+// kin_threshold > 1.6 / sqrt(sites).  Either form gives the same records.
+bool use_full_counts(const cuking_ctx *ctx, float kin_threshold, bool dense,
+                     uint32_t words_per_sample) {
   if (dense || ctx->counts_mode == 1) return true;
   if (ctx->counts_mode == 0) return false;
-  return !(kin_threshold > 0.0f);
+  if (!(kin_threshold > 0.0f)) return true;
+  const double sites = 32.0 * words_per_sample;
+  return (double)kin_threshold * kin_threshold * sites < 1.6 * 1.6;
 }
 
 cuking_status bind(cuking_ctx *ctx) {
@@ -289,7 +296,7 @@ cuking_status run_tiled(cuking_ctx *ctx, const cuking_submatrix &sm,
   EventPair *ev = nullptr;
   if (ctx->timing) HIP_TRY(ctx->king_timer.begin(stream, &ev));
   HIP_TRY(launch_tiled(ctx->variant,
-                       use_full_counts(ctx, kin_threshold, d_counts != nullptr), a,
+                       use_full_counts(ctx, kin_threshold, d_counts != nullptr, words_per_sample), a,
                        tile_end - tile_begin, stream));
   if (ev) HIP_TRY(hipEventRecord(ev->stop, stream));
   return CUKING_OK;
@@ -822,7 +829,7 @@ cuking_status cuking_compute_king_rect(
   a.words_per_sample = words_per_sample;
   EventPair *ev = nullptr;
   if (ctx->timing) HIP_TRY(ctx->king_timer.begin((hipStream_t)stream, &ev));
-  HIP_TRY(launch_tiled(ctx->variant, use_full_counts(ctx, kin_threshold, false), a,
+  HIP_TRY(launch_tiled(ctx->variant, use_full_counts(ctx, kin_threshold, false, words_per_sample), a,
                        (uint64_t)n_rows * (c1 - c0), (hipStream_t)stream));
   if (ev) HIP_TRY(hipEventRecord(ev->stop, (hipStream_t)stream));
   return CUKING_OK;
