@@ -158,7 +158,11 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
-    if world > 1:
+    # CUKING_BENCH_FORCE_DIST=1: run the multi-GPU code path (process group,
+    # collectives) even with one rank -- a one-GPU check of the RCCL calls.
+    force_dist = os.environ.get("CUKING_BENCH_FORCE_DIST") == "1"
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearsal:
             dist.init_process_group("gloo")
@@ -192,7 +196,7 @@ def main():
     results = torch.zeros((args.max_results, 6), dtype=torch.int32, device=dev)
     index_flag = torch.zeros(2, dtype=torch.int32, device=dev)
     num_tiles = ctx.num_tiles(sm) if args.kernel == "tiled" else 0
-    my_tiles = tile_partition(num_tiles, world)[rank] if world > 1 else None
+    my_tiles = tile_partition(num_tiles, world)[rank] if use_dist else None
 
     def compute_tiles(bit_sets, begin, end):
         index_flag.zero_()
@@ -202,13 +206,13 @@ def main():
         return results, count, ovf
 
     gathered = [None]
-    staged = world > 1 and args.dist_mode == "staged" and args.kernel == "tiled"
+    staged = use_dist and args.dist_mode == "staged" and args.kernel == "tiled"
     tile = ctx.tile_samples()
     staged_ops = (GpuStagedOps(ctx, sm, wps, bits, thr, args.max_results)
                   if staged else None)
 
     def step():
-        if world == 1:
+        if not use_dist:
             index_flag.zero_()
             ctx.compute_king(sm, wps, bits, thr, args.max_results, results,
                              index_flag[0:1], index_flag[1:2])
@@ -219,7 +223,7 @@ def main():
             gathered[0], _ = all_pairs_king(compute_tiles, num_tiles, bits)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -232,14 +236,14 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
 
     timing = ctx.timing_collect()
     # Records of the last step (rank 0): sanity + parity material.
-    if world == 1:
+    if not use_dist:
         count, ovf = index_flag.tolist()
         if ovf:
             raise SystemExit("result overflow: raise --max-results")
@@ -262,7 +266,7 @@ def main():
         bpp = cuking_amd.bytes_per_pair(wps)
         # Dominant kernel = the pair kernel; rank 0's launches cover its own
         # share of the pairs.
-        if world == 1:
+        if not use_dist:
             launch_pairs, launches = pairs, timing.king_launches
         else:
             # rank 0's share of the pairs per step; its kernel time per step is
@@ -280,7 +284,7 @@ def main():
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": load_traffic(key) if world == 1 else None,
+            "traffic": load_traffic(key) if not use_dist else None,
             "kernel": f"king_{args.kernel}_kernel",
             "kernel_ms": king_ms, "launches": timing.king_launches,
             "algorithmic_bytes_per_pair": bpp,
@@ -313,17 +317,17 @@ def main():
                        "results_per_step": int(len(recs)),
                        "kernel": args.kernel,
                        "parallelism": f"pair-space tiles over {world} GPU(s)"
-                                      + (f", {args.dist_mode} bitset broadcast" if world > 1 else "")},
+                                      + (f", {args.dist_mode} bitset broadcast" if use_dist else "")},
             "roofline": roofline,
         }
-        if world == 1 and args.cpu_seconds > 0:
+        if not use_dist and args.cpu_seconds > 0:
             def host_bits(s):
                 return np.ascontiguousarray(bits[:s].cpu().numpy().view(np.uint64))
             out["cpu_baseline"] = cpu_baseline(host_bits, wps, recs, thr, args.cpu_seconds,
                                                n, args.cpu_threads)
         else:
             out["cpu_baseline"] = None
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:

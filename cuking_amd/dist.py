@@ -161,7 +161,10 @@ def all_pairs_king_staged(ops, num_samples: int, tile: int, bit_sets,
     ``compute_rect((r0, r1, step), (c0, c1))`` and ``finish() -> (records, count,
     overflow)``.  Returns (sorted records on dst else None, the rank's schedule)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
+    # With a process group (even of one rank) the collectives are issued, so a
+    # single-rank nccl run exercises the same calls as an 8-rank one.
+    use_dist = dist.is_available() and dist.is_initialized()
+    if use_dist:
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     else:
         rank, world = 0, 1
@@ -170,9 +173,9 @@ def all_pairs_king_staged(ops, num_samples: int, tile: int, bit_sets,
     ops.begin()
     # All chunk broadcasts are enqueued up front; they complete in order.
     works = [dist.broadcast(bit_sets[c0:c1], src=src, group=group, async_op=True)
-             for (c0, c1), _ in steps] if world > 1 else []
+             for (c0, c1), _ in steps] if use_dist else []
     for k, ((c0, c1), rect) in enumerate(steps):
-        if world > 1 and rank != src:
+        if use_dist and rank != src:
             works[k].wait()        # nccl: the current stream waits, not the host
         if rect is None:
             continue               # this rank never reads these samples
@@ -181,7 +184,7 @@ def all_pairs_king_staged(ops, num_samples: int, tile: int, bit_sets,
     for w in works:                # the source's sends, too, before reuse
         w.wait()
     local, count, overflow = ops.finish()
-    if world == 1:
+    if not use_dist:
         if overflow:
             raise ResourceExhaustedError(
                 "Could not store all results: try increasing the --max_results "
