@@ -90,12 +90,12 @@ struct TiledArgs {
   const uint64_t *band_prefix;  // device; num_bands + 1 entries
   uint64_t tile_begin;          // first tile of this launch
   // Rectangle mode (rect_rows != 0): the launch covers the rect_rows tile rows
-  // rect_row0 + k * rect_row_stride x tile columns [rect_col0, ...),
-  // column-major; launch index t -> (rect_row0 + (t % rect_rows) * stride,
-  // rect_col0 + t / rect_rows).  Used to start on the columns whose samples
+  // rect_row0 + k * rect_row_stride x the rect_cols tile columns from
+  // rect_col0, enumerated in bands of band_rows rows, column-major inside a
+  // band.  Used to start on the columns whose samples
   // have already arrived while the rest of the bitset is still in flight; the
   // stride lets the ranks of a node take tile rows round-robin.
-  uint32_t rect_rows, rect_row0, rect_col0, rect_row_stride;
+  uint32_t rect_rows, rect_cols, rect_row0, rect_col0, rect_row_stride;
   uint32_t i_begin, j_begin;    // global sample index of row / column 0
   float kin_threshold;
   uint32_t max_results;

@@ -193,8 +193,17 @@ __global__ __launch_bounds__(TIT *TJT, MINW) void king_tiled_kernel(
   const uint64_t t = a.tile_begin + blockIdx.x;
   uint32_t tr, tc;
   if (a.rect_rows != 0) {
-    tr = a.rect_row0 + (uint32_t)(t % a.rect_rows) * a.rect_row_stride;
-    tc = a.rect_col0 + (uint32_t)(t / a.rect_rows);
+    // Rectangle mode: bands of band_rows rows of the rectangle, column-major
+    // inside a band (same locality as the whole-block enumeration).  Only the
+    // last band can be shorter.
+    const uint32_t g = a.tiles.band_rows;
+    const uint64_t per_band = (uint64_t)g * a.rect_cols;
+    const uint32_t b = (uint32_t)(t / per_band);
+    const uint32_t r0 = b * g;
+    const uint32_t h = a.rect_rows - r0 < g ? a.rect_rows - r0 : g;
+    const uint64_t u = t - (uint64_t)b * per_band;
+    tr = a.rect_row0 + (r0 + (uint32_t)(u % h)) * a.rect_row_stride;
+    tc = a.rect_col0 + (uint32_t)(u / h);
     // Below the diagonal of a diagonal block: nothing to do.  The whole
     // workgroup leaves here, before any barrier.
     if (a.tiles.diag && tc < tr) return;
