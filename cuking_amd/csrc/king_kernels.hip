@@ -238,8 +238,24 @@ __global__ __launch_bounds__(TIT *TJT, MINW) void king_tiled_kernel(
                          lane;
       uint4 *dst = lds + ((buf * 2 + side) * KC + kc) * TILE + seg * 64;
       // LDS-DMA: lane l's 16 bytes land at dst + 16 * l.
-      __builtin_amdgcn_global_load_lds((global_void_ptr)src, (lds_void_ptr)dst,
-                                       16, 0, 0);
+      if (PHASED) {
+        // Issued through inline asm so that the compiler's wait-count pass does
+        // not know about it: otherwise every ds_read that follows (they read
+        // the OTHER buffer) is preceded by s_waitcnt vmcnt(0), i.e. waits for
+        // the chunk that was just requested.  The hand-placed vmcnt(0) in
+        // front of the chunk barrier below is the only wait this needs.
+        const uint32_t lds_addr = (uint32_t)(uintptr_t)(lds_void_ptr)dst;
+        asm volatile(
+            "s_mov_b32 m0, %0\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off"
+            :
+            : "s"(lds_addr), "v"(src)
+            : "memory");  // (M0 has no other user in this kernel on gfx950)
+      } else {
+        __builtin_amdgcn_global_load_lds((global_void_ptr)src, (lds_void_ptr)dst,
+                                         16, 0, 0);
+      }
     }
   };
 
