@@ -580,3 +580,20 @@ def test_streams_from_the_abi(ctx, oracle):
     exp, _, _ = oracle.compute(oracle.submatrix(130), bits, 0.02)
     assert host_idx[0] == len(exp) and host_idx[1] == 0
     assert ctx.lib.cuking_stream_destroy(ctx.handle, stream) == 0
+
+
+def test_c1_sample_order_symmetry(ctx, c1):
+    """Size-independent property at full size: KING is symmetric in the pair, so
+    reversing the sample order must give the same (kin, ibs0, ibs1, ibs2) for the
+    mirrored pair (n-1-j, n-1-i) -- every pair then meets the kernel with rows
+    and columns, tiles and lanes exchanged."""
+    n, bits = c1["n"], c1["bits"]
+    select(ctx, "tiled", 0)
+    rev = ctx.run(cuking_amd.Submatrix(n), bits.shape[1], bits.flip(0).contiguous(), 0.05)
+    res = c1["res"]
+    assert len(rev) == len(res)
+    mirrored = rev.copy()
+    mirrored["sample_i"] = n - 1 - rev["sample_j"]
+    mirrored["sample_j"] = n - 1 - rev["sample_i"]
+    mirrored = cuking_amd.sort_results(np.ascontiguousarray(mirrored))
+    assert mirrored.tobytes() == res.tobytes()
