@@ -69,7 +69,7 @@ def parse_args():
                     help="N>1: overlap the chunked bitset broadcast with compute "
                          "(staged) or broadcast first (simple)")
     ap.add_argument("--chunks", type=int, default=8, help="broadcast chunks (staged)")
-    ap.add_argument("--streams", type=int, default=2, help="side streams for rectangle launches")
+    ap.add_argument("--streams", type=int, default=3, help="side streams for rectangle launches")
     ap.add_argument("--no-check", action="store_true",
                     help="skip the planted-relatives check (timing-only tuning kernels)")
     ap.add_argument("--seed", type=int, default=20240229)

@@ -201,7 +201,7 @@ class GpuStagedOps:
     into one buffer."""
 
     def __init__(self, ctx, submatrix, words_per_sample: int, bit_sets,
-                 kin_threshold: float, max_results: int, num_streams: int = 2):
+                 kin_threshold: float, max_results: int, num_streams: int = 3):
         import torch
         self.ctx, self.sm, self.wps, self.bits = ctx, submatrix, words_per_sample, bit_sets
         self.thr, self.max_results = kin_threshold, max_results
