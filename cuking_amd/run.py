@@ -45,6 +45,10 @@ def parse_args(argv=None):
     flag("split-factor", type=int, default=1)
     flag("shard-index", type=int, default=0)
     flag("chunks", type=int, default=8)
+    flag("synthetic", default="",
+         help="N,M[,seed]: instead of reading --input-uri, generate the synthetic cohort of "
+              "cuking_amd.synth on the GPU (BASELINE configs without their 10^9..10^11-row "
+              "Parquet form)")
     return ap.parse_args(argv)
 
 
@@ -60,7 +64,7 @@ def resolve_uri(uri: str) -> Path:
 
 
 def validate(args):  # cuking.cu:437-462
-    if not args.input_uri:
+    if not args.input_uri and not args.synthetic:
         raise UsageError("No input URI specified")
     if not args.output_uri:
         raise UsageError("No output URI specified")
@@ -143,7 +147,18 @@ def main(argv=None) -> int:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     try:
         validate(args)
-        in_dir, out_dir = resolve_uri(args.input_uri), resolve_uri(args.output_uri)
+        in_dir = resolve_uri(args.input_uri) if args.input_uri else None
+        out_dir = resolve_uri(args.output_uri)
+        synthetic = None
+        if args.synthetic:
+            parts = [int(x) for x in args.synthetic.split(",")]
+            if len(parts) not in (2, 3) or min(parts[:2]) <= 0:
+                raise UsageError("--synthetic expects N,M[,seed]")
+            synthetic = (parts[0], parts[1], parts[2] if len(parts) == 3 else 20240229)
+    except ValueError:
+        if rank == 0:
+            print("\nError: INVALID_ARGUMENT: --synthetic expects N,M[,seed]", file=sys.stderr)
+        return 1
     except UsageError as e:
         if rank == 0:
             print(f"\nError: INVALID_ARGUMENT: {e}", file=sys.stderr)
@@ -155,8 +170,12 @@ def main(argv=None) -> int:
         dist.init_process_group("nccl", device_id=torch.device(dev))
     try:
         t0 = time.perf_counter()
-        meta = json.loads((in_dir / "metadata.json").read_text())
-        sample_ids, num_sites = list(meta["samples"]), int(meta["num_sites"])
+        if synthetic:
+            sample_ids = [f"S{k:07d}" for k in range(synthetic[0])]
+            num_sites = synthetic[1]
+        else:
+            meta = json.loads((in_dir / "metadata.json").read_text())
+            sample_ids, num_sites = list(meta["samples"]), int(meta["num_sites"])
         sm = cuking_amd.Submatrix(len(sample_ids), args.split_factor, args.shard_index)
         wps = cuking_amd.words_per_sample(num_sites)
         ctx = cuking_amd.KingContext(local_rank)
@@ -167,9 +186,21 @@ def main(argv=None) -> int:
         pack_error = None
         if rank == 0:
             try:
-                host = read_and_pack(in_dir, sm, num_sites, args.num_reader_threads)
-                if stored:
-                    bits[:stored].copy_(torch.from_numpy(host.view(np.int64)))
+                if synthetic:
+                    from cuking_amd.synth import cohort_to_device, plan_cohort
+                    kind, pa, pb = cohort_to_device(plan_cohort(synthetic[0], synthetic[2]),
+                                                    local_rank)
+                    # the block's samples, rows first then columns (cuking.cu:171-175)
+                    ctx.synth_bitset(synthetic[2], kind, pa, pb, sm.i_begin, sm.i_end,
+                                     num_sites, out=bits[:sm.NumRows()])
+                    if sm.i_begin != sm.j_begin:
+                        ctx.synth_bitset(synthetic[2], kind, pa, pb, sm.j_begin, sm.j_end,
+                                         num_sites, out=bits[sm.NumRows():stored])
+                    torch.cuda.synchronize()
+                else:
+                    host = read_and_pack(in_dir, sm, num_sites, args.num_reader_threads)
+                    if stored:
+                        bits[:stored].copy_(torch.from_numpy(host.view(np.int64)))
                 print(f"[cuking_amd.run] packed {stored} samples x {num_sites} sites "
                       f"({time.perf_counter() - t0:.2f}s)", flush=True)
             except Exception as e:  # noqa: BLE001 - reported below on every rank

@@ -399,3 +399,36 @@ def test_python_driver_flag_errors(tmp_path):
         p = subprocess.run([sys.executable, "-m", "cuking_amd.run", *argv],
                            capture_output=True, text=True, timeout=300, cwd=root)
         assert p.returncode == 1 and f"Error: INVALID_ARGUMENT: {msg}" in p.stderr, p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,shard", [(1, 0), (2, 1)])
+def test_python_driver_synthetic_mode(tmp_path, oracle, k, shard):
+    """`--synthetic N,M,seed` (BASELINE configs without their Parquet form):
+    device generator -> kernel -> Parquet, checked against the oracle twin."""
+    import subprocess
+    import sys
+    import pyarrow.parquet as pq
+    from cuking_amd.synth import plan_cohort
+    n, m, seed, thr = 600, 3000, 5, 0.06
+    out = tmp_path / "out"
+    p = subprocess.run([sys.executable, "-m", "cuking_amd.run", "--output-uri", str(out),
+                        "--synthetic", f"{n},{m},{seed}", f"--kin-threshold={thr}",
+                        f"--split-factor={k}", f"--shard-index={shard}"],
+                       capture_output=True, text=True, timeout=600,
+                       cwd=str(Path(__file__).resolve().parent.parent))
+    assert p.returncode == 0, p.stderr
+    cohort = plan_cohort(n, seed)
+    bits = oracle.synth_bitset(seed, cohort.kind, cohort.pa, cohort.pb, 0, n, m)
+    osm = oracle.submatrix(n, k, shard)
+    idx = list(range(osm.i_begin, osm.i_end))
+    if osm.i_begin != osm.j_begin:
+        idx += list(range(osm.j_begin, osm.j_end))
+    exp, _, _ = oracle.compute(osm, np.ascontiguousarray(bits[idx]), thr)
+    t = pq.read_table(out / f"part-{shard:05d}.snappy.parquet")
+    assert t.num_rows == len(exp) > 0
+    assert t.column("i").to_pylist() == [f"S{x:07d}" for x in exp["sample_i"]]
+    assert t.column("j").to_pylist() == [f"S{x:07d}" for x in exp["sample_j"]]
+    assert np.array_equal(t.column("kin").to_numpy().view(np.uint32), exp["kin"].view(np.uint32))
+    for name in ("ibs0", "ibs1", "ibs2"):
+        assert np.array_equal(t.column(name).to_numpy().astype(np.uint32), exp[name])
