@@ -435,7 +435,9 @@ Status Run(const Flags &flags) {
             << ", \"kernel_seconds\": "
             << std::setprecision(6) << kernel_seconds << ", \"pairs_per_second\": "
             << std::setprecision(1) << rate << ", \"algorithmic_GBps\": "
-            << rate * cuking_bytes_per_pair(words_per_sample) / 1e9 << "}" << std::endl;
+            << rate * cuking_bytes_per_pair(words_per_sample) / 1e9
+            << ", \"hbm_roofline_fraction\": " << std::setprecision(3)
+            << rate * cuking_bytes_per_pair(words_per_sample) / 8e12 << "}" << std::endl;
   return Status::Ok();
 }
 
