@@ -114,11 +114,20 @@ def cpu_baseline(host_bits_fn, wps, gpu_records, thr, target_seconds, max_sample
     if sel.tobytes() != res.tobytes():
         raise SystemExit(f"PARITY FAILURE: GPU records for the first {s} samples "
                          "differ from the CPU oracle")
+    cpu_model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": pairs / dt, "unit": "sample-pairs/s", "cores": threads,
             "kind": "port",
             "sample": f"first {s} samples ({pairs} pairs) of the same cohort, "
-                      f"{dt:.1f} s, OpenMP x{threads}, -O3 -march=native; "
-                      "records checked equal to the GPU's"}
+                      f"{dt:.1f} s, OpenMP x{threads} on {cpu_model} "
+                      f"({len(os.sched_getaffinity(0))} hardware threads visible), "
+                      "-O3 -march=native; records checked equal to the GPU's"}
 
 
 def load_traffic(workload_key):
