@@ -22,7 +22,7 @@ INCLUDE = ROOT / "include"
 LIB_PATH = PKG / "libcuking_amd.so"
 CLI_PATH = PKG / "bin" / "cuking"
 
-HIP_SOURCES = ["king_abi.hip", "king_kernels.hip", "synth.hip"]
+HIP_SOURCES = ["king_abi.hip", "king_kernels.hip", "king_mfma.hip", "synth.hip"]
 # IEEE-correct fp32 divide (kinship must match the reference bit for bit):
 # no fast-math, no contraction, correctly rounded divide/sqrt stays on.
 HIP_FLAGS = [
@@ -51,7 +51,8 @@ def build_library(force: bool = False, save_temps: bool = False,
     """tuning=True adds timing-only experiment kernels (-DCUKING_TUNING); never
     the shipped configuration (build() and the tests use the default)."""
     srcs = [CSRC / s for s in HIP_SOURCES]
-    deps = srcs + [CSRC / "king_common.h", INCLUDE / "cuking_amd.h",
+    deps = srcs + [CSRC / "king_common.h", CSRC / "king_device.h",
+                   INCLUDE / "cuking_amd.h",
                    Path(__file__)]
     if not force and _newer(LIB_PATH, deps):
         return LIB_PATH

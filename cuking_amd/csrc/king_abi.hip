@@ -209,6 +209,11 @@ cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
   const TileSpace tiles = make_tiles(geo, v, ctx->band_rows);
   *geo_out = geo;
   *tiles_out = tiles;
+  if (v.layout == kLayoutQuad && (uint64_t)geo.k_words * 32 > kMfmaMaxSites)
+    return fail(CUKING_ERR_FAILED_PRECONDITION,
+                "variant %s counts in float32 and is exact up to %u sites; "
+                "this bitset has %llu: select variant 0",
+                v.name, kMfmaMaxSites, (unsigned long long)geo.k_words * 32);
 
   const size_t need = (size_t)geo.k_words * geo.s_stride * sizeof(uint4);
   if (need > ctx->planes_bytes) {
@@ -249,7 +254,7 @@ cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
   if (need == 0) return CUKING_OK;
   EventPair *ev = nullptr;
   if (ctx->timing) HIP_TRY(ctx->prepare_timer.begin(stream, &ev));
-  HIP_TRY(launch_prepare_planes(d_bit_sets, words_per_sample, geo, ctx->planes,
+  HIP_TRY(launch_prepare_planes(v.layout, d_bit_sets, words_per_sample, geo, ctx->planes,
                                 s_tile_begin, s_tile_end, stream));
   if (ev) HIP_TRY(hipEventRecord(ev->stop, stream));
   return CUKING_OK;

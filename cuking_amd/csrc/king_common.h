@@ -23,7 +23,19 @@ namespace cuking {
 // diagonal block col_base = 0 and the samples are stored once (cuking.cu:161).
 // Padding samples and padding k-words are all-zero (= everything missing),
 // so they add nothing to any sum.
+//
+// Quad layout (kLayoutQuad, the matrix-core kernel): for every quad q of four
+// consecutive 32-site words, plane p and sample s one uint4 holding those four
+// words of ONE plane, planes[(q * 4 + p) * s_stride + s], with the planes
+//     p = 0  A   hom-alt                  (hom_var & ~het)
+//     p = 1  R   hom-ref                  (~het & ~hom_var)
+//     p = 2  H   het and defined          (het & ~hom_var)
+//     p = 3  D   defined                  ~(het & hom_var)
+// Same bytes per sample and site, same padding rules.
 // ---------------------------------------------------------------------------
+constexpr uint32_t kLayoutWord = 0;
+constexpr uint32_t kLayoutQuad = 1;
+
 struct PlaneGeometry {
   uint32_t num_rows, num_cols;        // block shape in samples
   uint32_t rows_padded, cols_padded;  // rounded up to the tile edge
@@ -116,13 +128,19 @@ struct TiledVariant {
   uint32_t k_chunk;   // 32-site words staged per LDS buffer
   uint32_t threads;   // workgroup size
   uint32_t lds_bytes; // dynamic LDS
+  uint32_t layout;    // kLayoutWord / kLayoutQuad
 };
 
+// The matrix-core variant accumulates in float32: exact while every sum stays
+// below 2^24.
+constexpr uint32_t kMfmaMaxSites = 1u << 24;
+
 #ifdef CUKING_TUNING
-constexpr int kNumTiledVariants = 11;  // + timing-only experiments
+constexpr int kNumTiledVariants = 12;  // + timing-only experiments
 #else
-constexpr int kNumTiledVariants = 5;
+constexpr int kNumTiledVariants = 6;
 #endif
+constexpr int kMfmaVariant = 5;
 const TiledVariant &tiled_variant(int v);
 // Enqueues tiles [args.tile_begin, args.tile_begin + num_tiles).
 // full = accumulate all five sums for every pair (needed for the diagnostic
@@ -131,13 +149,16 @@ const TiledVariant &tiled_variant(int v);
 // emitted pairs only.  Same records either way.
 hipError_t launch_tiled(int variant, bool full, const TiledArgs &args,
                         uint64_t num_tiles, hipStream_t stream);
+// The matrix-core kernel (king_mfma.hip); reached through launch_tiled.
+hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
+                       uint32_t lds_bytes, hipStream_t stream);
 
 // Converts plane-sample tiles [s_tile_begin, s_tile_end) (units of 64 plane
 // samples) of the block.
 // Test hook: cap the workgroups per launch (0 = hardware limit only).
 void set_max_blocks_per_launch(uint64_t blocks);
 
-hipError_t launch_prepare_planes(const uint64_t *d_bit_sets,
+hipError_t launch_prepare_planes(uint32_t layout, const uint64_t *d_bit_sets,
                                  uint32_t words_per_sample,
                                  const PlaneGeometry &geo, uint4 *d_planes,
                                  uint32_t s_tile_begin, uint32_t s_tile_end,

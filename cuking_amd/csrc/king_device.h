@@ -1,0 +1,161 @@
+// Device-side pieces shared by the pair kernels (king_kernels.hip,
+// king_mfma.hip): tile decoding, the kinship arithmetic, the record append and
+// the per-emitted-pair recount.
+#ifndef CUKING_AMD_KING_DEVICE_H_
+#define CUKING_AMD_KING_DEVICE_H_
+
+#include <hip/hip_runtime.h>
+
+#include "king_common.h"
+
+namespace cuking {
+
+typedef __attribute__((address_space(3))) void *lds_void_ptr;
+typedef const __attribute__((address_space(1))) void *global_void_ptr;
+
+// cuking.cu:289-294: two float32 roundings (divide, add).  Numerator and
+// denominator are exact integers (< 2^24 for < 2^22 sites); the divide is the
+// IEEE-correct one (no fast-math, see build flags).  min == 0 gives -inf or
+// NaN, which fails `kin > threshold`.
+__device__ __forceinline__ float king_kinship(uint32_t het_i, uint32_t het_j,
+                                              uint32_t both_het,
+                                              uint32_t opposing_hom) {
+  const uint32_t min_hets = het_i < het_j ? het_i : het_j;
+  const float num = 2.f * (float)both_het - 4.f * (float)opposing_hom -
+                    (float)het_i - (float)het_j;
+  const float den = 4.f * (float)min_hets;
+  return 0.5f + num / den;
+}
+
+// cuking.cu:297-313: reserve a slot, store or flag overflow.
+__device__ __forceinline__ void emit_result(uint32_t i, uint32_t j, float kin,
+                                            uint32_t ibs0, uint32_t ibs1,
+                                            uint32_t ibs2, uint32_t max_results,
+                                            cuking_result *results,
+                                            uint32_t *result_index,
+                                            uint32_t *result_overflow) {
+  const uint32_t slot = atomicAdd(result_index, 1u);
+  if (slot < max_results) {
+    cuking_result r;
+    r.sample_i = i;
+    r.sample_j = j;
+    r.kin = kin;
+    r.ibs0 = ibs0;
+    r.ibs1 = ibs1;
+    r.ibs2 = ibs2;
+    results[slot] = r;
+  } else {
+    atomicMax(result_overflow, 1u);
+  }
+}
+
+// Sites where both samples are homozygous (hom-ref or hom-alt), counted by one
+// whole wavefront straight from the reference layout: ~het is "homozygous and
+// defined" (missing and padding sites have the het bit set, cuking.cu:688-697).
+// Every lane gets the sum.
+__device__ __forceinline__ uint32_t wave_hom_hom_count(
+    const uint64_t *__restrict__ bits, uint32_t words_per_sample,
+    uint32_t offset_i, uint32_t offset_j, uint32_t lane) {
+  const uint32_t n = words_per_sample / 2;
+  const uint64_t *het_i = bits + (uint64_t)offset_i * words_per_sample;
+  const uint64_t *het_j = bits + (uint64_t)offset_j * words_per_sample;
+  uint32_t c = 0;
+  for (uint32_t w = lane; w < n; w += 64) c += __popcll(~(het_i[w] | het_j[w]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+  return c;
+}
+
+// Which tile workgroup `t` of the launch owns (uniform across the workgroup).
+// Returns false when there is nothing to do (rectangle mode, below the
+// diagonal of a diagonal block): the whole workgroup must then leave before
+// any barrier.
+__device__ __forceinline__ bool decode_tile(const TiledArgs &a, uint64_t t,
+                                            uint32_t *tr, uint32_t *tc) {
+  if (a.rect_rows != 0) {
+    // Rectangle mode: bands of band_rows rows of the rectangle, column-major
+    // inside a band (same locality as the whole-block enumeration).  Only the
+    // last band can be shorter.
+    const uint32_t g = a.tiles.band_rows;
+    const uint64_t per_band = (uint64_t)g * a.rect_cols;
+    const uint32_t b = (uint32_t)(t / per_band);
+    const uint32_t r0 = b * g;
+    const uint32_t h = a.rect_rows - r0 < g ? a.rect_rows - r0 : g;
+    const uint64_t u = t - (uint64_t)b * per_band;
+    *tr = a.rect_row0 + (r0 + (uint32_t)(u % h)) * a.rect_row_stride;
+    *tc = a.rect_col0 + (uint32_t)(u / h);
+    return !(a.tiles.diag && *tc < *tr);
+  }
+  uint32_t lo = 0, hi = a.tiles.num_bands();
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (a.band_prefix[mid] <= t) lo = mid; else hi = mid;
+  }
+  a.tiles.decode(lo, t - a.band_prefix[lo], tr, tc);
+  return true;
+}
+
+// Lean epilogue of one pair held by every lane (cuking.cu:284-313): the main
+// loop kept the four sums kinship needs.  IBS0 and IBS1 follow from them
+// (ibs1 = exactly one het = hi + hj - 2 bh); IBS2 needs the hom/hom count,
+// which the whole wavefront sums for each of the (few) pairs that pass the
+// threshold.  Must be called by all 64 lanes.
+__device__ __forceinline__ void lean_epilogue_pair(
+    const TiledArgs &a, bool valid, uint32_t li, uint32_t lj, uint32_t het_i,
+    uint32_t het_j, uint32_t both_het, uint32_t opp, uint32_t lane) {
+  const float kin = king_kinship(het_i, het_j, both_het, opp);
+  const bool emit = valid && kin > a.kin_threshold;
+  unsigned long long pending = __ballot(emit);  // wave-uniform
+  uint32_t hom_hom = 0;
+  while (pending) {
+    const int src = __builtin_ctzll(pending);
+    pending &= pending - 1;
+    const uint32_t p_li = __builtin_amdgcn_readlane(li, src);
+    const uint32_t p_lj = __builtin_amdgcn_readlane(lj, src);
+    const uint32_t off_j = a.geo.diag ? p_lj : a.geo.num_rows + p_lj;
+    const uint32_t sum =
+        wave_hom_hom_count(a.bits, a.words_per_sample, p_li, off_j, lane);
+    if ((int)lane == src) hom_hom = sum;
+  }
+  if (emit) {
+    const uint32_t ibs0 = opp, ibs2 = hom_hom - opp + both_het;
+    emit_result(a.i_begin + li, a.j_begin + lj, kin, ibs0,
+                het_i + het_j - 2 * both_het, ibs2, a.max_results, a.results,
+                a.result_index, a.result_overflow);
+  }
+}
+
+// Full epilogue of one pair: all six reference sums from the five kept ones.
+__device__ __forceinline__ void full_epilogue_pair(
+    const TiledArgs &a, bool valid, uint32_t li, uint32_t lj, uint32_t het_i,
+    uint32_t het_j, uint32_t both_het, uint32_t opp, uint32_t hom_hom) {
+  if (!valid) return;
+  const uint32_t conc = hom_hom - opp;
+  const uint32_t shared = het_i + het_j - both_het + hom_hom;
+  if (a.dense_counts != nullptr) {
+    cuking_counts c;
+    c.het_i = het_i;
+    c.het_j = het_j;
+    c.both_het = both_het;
+    c.opposing_hom = opp;
+    c.concordant_hom = conc;
+    c.shared = shared;
+    a.dense_counts[(uint64_t)li * a.geo.num_cols + lj] = c;
+    return;
+  }
+  const float kin = king_kinship(het_i, het_j, both_het, opp);
+  if (kin > a.kin_threshold) {
+    const uint32_t ibs0 = opp, ibs2 = conc + both_het;
+    emit_result(a.i_begin + li, a.j_begin + lj, kin, ibs0, shared - ibs0 - ibs2,
+                ibs2, a.max_results, a.results, a.result_index,
+                a.result_overflow);
+  }
+}
+
+// Workgroups per launch: one launch may not exceed 2^32 - 1 threads in x (HIP
+// truncates silently beyond that); tests can lower the cap.
+uint64_t max_blocks_per_launch(uint32_t threads);
+
+}  // namespace cuking
+
+#endif  // CUKING_AMD_KING_DEVICE_H_

@@ -15,66 +15,11 @@
 #include <hip/hip_runtime.h>
 
 #include "king_common.h"
+#include "king_device.h"
 
 namespace cuking {
 
 namespace {
-
-typedef __attribute__((address_space(3))) void *lds_void_ptr;
-typedef const __attribute__((address_space(1))) void *global_void_ptr;
-
-// cuking.cu:289-294: two float32 roundings (divide, add).  Numerator and
-// denominator are exact integers (< 2^24 for < 2^22 sites); the divide is the
-// IEEE-correct one (no fast-math, see build flags).  min == 0 gives -inf or
-// NaN, which fails `kin > threshold`.
-__device__ __forceinline__ float king_kinship(uint32_t het_i, uint32_t het_j,
-                                              uint32_t both_het,
-                                              uint32_t opposing_hom) {
-  const uint32_t min_hets = het_i < het_j ? het_i : het_j;
-  const float num = 2.f * (float)both_het - 4.f * (float)opposing_hom -
-                    (float)het_i - (float)het_j;
-  const float den = 4.f * (float)min_hets;
-  return 0.5f + num / den;
-}
-
-// cuking.cu:297-313: reserve a slot, store or flag overflow.
-__device__ __forceinline__ void emit_result(uint32_t i, uint32_t j, float kin,
-                                            uint32_t ibs0, uint32_t ibs1,
-                                            uint32_t ibs2, uint32_t max_results,
-                                            cuking_result *results,
-                                            uint32_t *result_index,
-                                            uint32_t *result_overflow) {
-  const uint32_t slot = atomicAdd(result_index, 1u);
-  if (slot < max_results) {
-    cuking_result r;
-    r.sample_i = i;
-    r.sample_j = j;
-    r.kin = kin;
-    r.ibs0 = ibs0;
-    r.ibs1 = ibs1;
-    r.ibs2 = ibs2;
-    results[slot] = r;
-  } else {
-    atomicMax(result_overflow, 1u);
-  }
-}
-
-// Sites where both samples are homozygous (hom-ref or hom-alt), counted by one
-// whole wavefront straight from the reference layout: ~het is "homozygous and
-// defined" (missing and padding sites have the het bit set, cuking.cu:688-697).
-// Every lane gets the sum.
-__device__ __forceinline__ uint32_t wave_hom_hom_count(
-    const uint64_t *__restrict__ bits, uint32_t words_per_sample,
-    uint32_t offset_i, uint32_t offset_j, uint32_t lane) {
-  const uint32_t n = words_per_sample / 2;
-  const uint64_t *het_i = bits + (uint64_t)offset_i * words_per_sample;
-  const uint64_t *het_j = bits + (uint64_t)offset_j * words_per_sample;
-  uint32_t c = 0;
-  for (uint32_t w = lane; w < n; w += 64) c += __popcll(~(het_i[w] | het_j[w]));
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-  return c;
-}
 
 // ---------------------------------------------------------------------------
 // prepare_planes_kernel
@@ -137,6 +82,66 @@ __global__ __launch_bounds__(256) void prepare_planes_kernel(
   }
 }
 
+// Same transpose into the quad layout of the matrix-core kernel: one uint4 =
+// four consecutive 32-site words (two u64 source words) of one plane.
+__global__ __launch_bounds__(256) void prepare_quads_kernel(
+    const uint64_t *__restrict__ bits, uint32_t words_per_sample,
+    PlaneGeometry geo, uint4 *__restrict__ planes, uint32_t s_tile_begin) {
+  __shared__ uint64_t het_lds[kPrepSamples][kPrepWords + 1];
+  __shared__ uint64_t hom_lds[kPrepSamples][kPrepWords + 1];
+
+  const uint32_t plane_words = words_per_sample / 2;
+  const uint32_t s0 = (s_tile_begin + blockIdx.x) * kPrepSamples;
+  const uint32_t w0 = blockIdx.y * kPrepWords;
+
+#pragma unroll
+  for (int it = 0; it < kPrepSamples * kPrepWords / 256; ++it) {
+    const uint32_t idx = it * 256 + threadIdx.x;
+    const uint32_t s = idx / kPrepWords, w = idx % kPrepWords;
+    const uint32_t ps = s0 + s;
+    uint32_t src = 0xFFFFFFFFu;
+    if (geo.diag || ps < geo.rows_padded) {
+      if (ps < geo.num_rows) src = ps;
+    } else {
+      const uint32_t c = ps - geo.col_base;
+      if (c < geo.num_cols) src = geo.num_rows + c;
+    }
+    uint64_t het = ~0ull, hom = ~0ull;  // missing
+    if (src != 0xFFFFFFFFu && w0 + w < plane_words) {
+      const uint64_t *p = bits + (uint64_t)src * words_per_sample + (w0 + w);
+      het = p[0];
+      hom = p[plane_words];
+    }
+    het_lds[s][w] = het;
+    hom_lds[s][w] = hom;
+  }
+  __syncthreads();
+
+  constexpr int kQuads = kPrepWords / 2;
+#pragma unroll
+  for (int it = 0; it < kQuads * 4 * kPrepSamples / 256; ++it) {
+    const uint32_t idx = it * 256 + threadIdx.x;
+    const uint32_t s = idx % kPrepSamples;
+    const uint32_t p = (idx / kPrepSamples) % 4;
+    const uint32_t ql = idx / (kPrepSamples * 4);
+    const uint32_t q = w0 / 2 + ql;
+    if (q * 4 >= geo.k_words || s0 + s >= geo.s_stride) continue;
+    uint64_t w[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint64_t het = het_lds[s][2 * ql + h], hom = hom_lds[s][2 * ql + h];
+      w[h] = p == 0 ? (hom & ~het) : p == 1 ? ~(het | hom)
+           : p == 2 ? (het & ~hom) : ~(het & hom);
+    }
+    uint4 v;
+    v.x = (uint32_t)w[0];
+    v.y = (uint32_t)(w[0] >> 32);
+    v.z = (uint32_t)w[1];
+    v.w = (uint32_t)(w[1] >> 32);
+    planes[((uint64_t)q * 4 + p) * geo.s_stride + s0 + s] = v;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // king_tiled_kernel
 //
@@ -192,29 +197,7 @@ __global__ __launch_bounds__(TIT *TJT, MINW) void king_tiled_kernel(
   // --- which tile (uniform across the workgroup) ---
   const uint64_t t = a.tile_begin + blockIdx.x;
   uint32_t tr, tc;
-  if (a.rect_rows != 0) {
-    // Rectangle mode: bands of band_rows rows of the rectangle, column-major
-    // inside a band (same locality as the whole-block enumeration).  Only the
-    // last band can be shorter.
-    const uint32_t g = a.tiles.band_rows;
-    const uint64_t per_band = (uint64_t)g * a.rect_cols;
-    const uint32_t b = (uint32_t)(t / per_band);
-    const uint32_t r0 = b * g;
-    const uint32_t h = a.rect_rows - r0 < g ? a.rect_rows - r0 : g;
-    const uint64_t u = t - (uint64_t)b * per_band;
-    tr = a.rect_row0 + (r0 + (uint32_t)(u % h)) * a.rect_row_stride;
-    tc = a.rect_col0 + (uint32_t)(u / h);
-    // Below the diagonal of a diagonal block: nothing to do.  The whole
-    // workgroup leaves here, before any barrier.
-    if (a.tiles.diag && tc < tr) return;
-  } else {
-    uint32_t lo = 0, hi = a.tiles.num_bands();
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (a.band_prefix[mid] <= t) lo = mid; else hi = mid;
-    }
-    a.tiles.decode(lo, t - a.band_prefix[lo], &tr, &tc);
-  }
+  if (!decode_tile(a, t, &tr, &tc)) return;  // before any barrier
 
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -398,62 +381,18 @@ __global__ __launch_bounds__(TIT *TJT, MINW) void king_tiled_kernel(
 #pragma unroll
   for (int x = 0; x < RI; ++x) {
     const uint32_t li = tr * TILE + x * TIT + ti;  // row inside the block
-    const uint32_t i = a.i_begin + li;
 #pragma unroll
     for (int y = 0; y < RJ; ++y) {
       const uint32_t lj = tc * TILE + y * TJT + tj;
-      const uint32_t j = a.j_begin + lj;
       // cuking.cu:199 plus the tile padding
-      const bool valid = li < a.geo.num_rows && lj < a.geo.num_cols && i < j;
-      const uint32_t het_i = c_hi[x][y], het_j = c_hj[x][y];
-      const uint32_t both_het = c_bh[x][y], opp = c_opp[x][y];
-      if (FULL) {
-        if (!valid) continue;
-        const uint32_t conc = c_hh[x][y] - opp;
-        const uint32_t shared = het_i + het_j - both_het + c_hh[x][y];
-        if (a.dense_counts != nullptr) {
-          cuking_counts c;
-          c.het_i = het_i;
-          c.het_j = het_j;
-          c.both_het = both_het;
-          c.opposing_hom = opp;
-          c.concordant_hom = conc;
-          c.shared = shared;
-          a.dense_counts[(uint64_t)li * a.geo.num_cols + lj] = c;
-          continue;
-        }
-        const float kin = king_kinship(het_i, het_j, both_het, opp);
-        if (kin > a.kin_threshold) {
-          const uint32_t ibs0 = opp, ibs2 = conc + both_het;
-          emit_result(i, j, kin, ibs0, shared - ibs0 - ibs2, ibs2, a.max_results,
-                      a.results, a.result_index, a.result_overflow);
-        }
-      } else {
-        // Lean pass: the main loop kept the four sums kinship needs.  IBS0 and
-        // IBS1 follow from them (ibs1 = exactly one het = hi + hj - 2 bh);
-        // IBS2 needs the hom/hom count, which the whole wavefront now sums
-        // for each of the (few) pairs that pass the threshold.
-        const float kin = king_kinship(het_i, het_j, both_het, opp);
-        const bool emit = valid && kin > a.kin_threshold;
-        unsigned long long pending = __ballot(emit);  // wave-uniform
-        uint32_t hom_hom = 0;
-        while (pending) {
-          const int src = __builtin_ctzll(pending);
-          pending &= pending - 1;
-          const uint32_t p_li = __builtin_amdgcn_readlane(li, src);
-          const uint32_t p_lj = __builtin_amdgcn_readlane(lj, src);
-          const uint32_t off_j = a.geo.diag ? p_lj : a.geo.num_rows + p_lj;
-          const uint32_t sum = wave_hom_hom_count(a.bits, a.words_per_sample,
-                                                  p_li, off_j, lane);
-          if ((int)lane == src) hom_hom = sum;
-        }
-        if (emit) {
-          const uint32_t ibs0 = opp, ibs2 = hom_hom - opp + both_het;
-          emit_result(i, j, kin, ibs0, het_i + het_j - 2 * both_het, ibs2,
-                      a.max_results, a.results, a.result_index,
-                      a.result_overflow);
-        }
-      }
+      const bool valid = li < a.geo.num_rows && lj < a.geo.num_cols &&
+                         a.i_begin + li < a.j_begin + lj;
+      if (FULL)
+        full_epilogue_pair(a, valid, li, lj, c_hi[x][y], c_hj[x][y], c_bh[x][y],
+                           c_opp[x][y], c_hh[x][y]);
+      else
+        lean_epilogue_pair(a, valid, li, lj, c_hi[x][y], c_hj[x][y], c_bh[x][y],
+                           c_opp[x][y], lane);
     }
   }
 }
@@ -576,11 +515,6 @@ __global__ __launch_bounds__(256) void pack_kernel(
 
 uint64_t g_max_blocks_override = 0;  // tests: force splitting at small sizes
 
-uint64_t max_blocks_per_launch(uint32_t threads) {
-  const uint64_t hw = 0xFFFFFFFFull / threads;
-  return (g_max_blocks_override && g_max_blocks_override < hw) ? g_max_blocks_override : hw;
-}
-
 template <int TIT, int TJT, int RI, int RJ, int KC, int KU, int MINW, bool FULL,
           int ABLATE = 0, int PHASED = 0>
 hipError_t launch_variant(const TiledArgs &args, uint64_t num_tiles,
@@ -611,18 +545,21 @@ hipError_t launch_variant(const TiledArgs &args, uint64_t num_tiles,
 }
 
 const TiledVariant kVariants[kNumTiledVariants] = {
-    {"t64_r4x2_k16_phased", 64, 16, 512, 2 * 2 * 16 * 64 * 16},
-    {"t64_r4x4_k8_w4", 64, 8, 256, 2 * 2 * 8 * 64 * 16},
-    {"t128_r8x4_k8_w2", 128, 8, 512, 2 * 2 * 8 * 128 * 16},
-    {"t128_r4x4_k8_w4", 128, 8, 1024, 2 * 2 * 8 * 128 * 16},
-    {"t64_r4x4_k16_w4", 64, 16, 256, 2 * 2 * 16 * 64 * 16},
+    {"t64_r4x2_k16_phased", 64, 16, 512, 2 * 2 * 16 * 64 * 16, kLayoutWord},
+    {"t64_r4x4_k8_w4", 64, 8, 256, 2 * 2 * 8 * 64 * 16, kLayoutWord},
+    {"t128_r8x4_k8_w2", 128, 8, 512, 2 * 2 * 8 * 128 * 16, kLayoutWord},
+    {"t128_r4x4_k8_w4", 128, 8, 1024, 2 * 2 * 8 * 128 * 16, kLayoutWord},
+    {"t64_r4x4_k16_w4", 64, 16, 256, 2 * 2 * 16 * 64 * 16, kLayoutWord},
+    // Matrix cores: 128 x 128 pairs per workgroup, 256 sites per k-step,
+    // three 32 KiB LDS stages (king_mfma.hip).
+    {"t128_mfma_fp4", 128, 8, 256, 3 * 2 * 2 * 4 * 128 * 16, kLayoutQuad},
 #ifdef CUKING_TUNING
-    {"phased_both_barriers", 64, 16, 512, 2 * 2 * 16 * 64 * 16},
-    {"phased_bar_before_popcount_only", 64, 16, 512, 2 * 2 * 16 * 64 * 16},
-    {"phased_k8", 64, 8, 512, 2 * 2 * 8 * 64 * 16},
-    {"unphased_noldsread", 64, 8, 256, 2 * 2 * 8 * 64 * 16},
-    {"unphased_nodma_nobarrier", 64, 8, 256, 2 * 2 * 8 * 64 * 16},
-    {"unphased_w5", 64, 8, 256, 2 * 2 * 8 * 64 * 16},
+    {"phased_both_barriers", 64, 16, 512, 2 * 2 * 16 * 64 * 16, kLayoutWord},
+    {"phased_bar_before_popcount_only", 64, 16, 512, 2 * 2 * 16 * 64 * 16, kLayoutWord},
+    {"phased_k8", 64, 8, 512, 2 * 2 * 8 * 64 * 16, kLayoutWord},
+    {"unphased_noldsread", 64, 8, 256, 2 * 2 * 8 * 64 * 16, kLayoutWord},
+    {"unphased_nodma_nobarrier", 64, 8, 256, 2 * 2 * 8 * 64 * 16, kLayoutWord},
+    {"unphased_w5", 64, 8, 256, 2 * 2 * 8 * 64 * 16, kLayoutWord},
 #endif
 };
 
@@ -630,6 +567,11 @@ const TiledVariant kVariants[kNumTiledVariants] = {
 }  // namespace
 
 void set_max_blocks_per_launch(uint64_t blocks) { g_max_blocks_override = blocks; }
+
+uint64_t max_blocks_per_launch(uint32_t threads) {
+  const uint64_t hw = 0xFFFFFFFFull / threads;
+  return (g_max_blocks_override && g_max_blocks_override < hw) ? g_max_blocks_override : hw;
+}
 
 const TiledVariant &tiled_variant(int v) { return kVariants[v]; }
 
@@ -649,13 +591,14 @@ hipError_t launch_tiled(int variant, bool full, const TiledArgs &args,
     case 2: return CUKING_SHAPE(16, 32, 8, 4, 8, 2, 2);
     case 3: return CUKING_SHAPE(32, 32, 4, 4, 8, 2, 4);
     case 4: return CUKING_SHAPE(16, 16, 4, 4, 16, 2, 4);
+    case kMfmaVariant: return launch_mfma(full, args, num_tiles, lds, stream);
 #ifdef CUKING_TUNING
-    case 5: return CUKING_PHASED(16, 2);
-    case 6: return CUKING_PHASED(16, 3);
-    case 7: return CUKING_PHASED(8, 1);
-    case 8: return launch_variant<16, 16, 4, 4, 8, 2, 4, false, 1>(args, num_tiles, lds, stream);
-    case 9: return launch_variant<16, 16, 4, 4, 8, 2, 4, false, 2>(args, num_tiles, lds, stream);
-    case 10: return launch_variant<16, 16, 4, 4, 8, 1, 5, false, 4>(args, num_tiles, lds, stream);
+    case 6: return CUKING_PHASED(16, 2);
+    case 7: return CUKING_PHASED(16, 3);
+    case 8: return CUKING_PHASED(8, 1);
+    case 9: return launch_variant<16, 16, 4, 4, 8, 2, 4, false, 1>(args, num_tiles, lds, stream);
+    case 10: return launch_variant<16, 16, 4, 4, 8, 2, 4, false, 2>(args, num_tiles, lds, stream);
+    case 11: return launch_variant<16, 16, 4, 4, 8, 1, 5, false, 4>(args, num_tiles, lds, stream);
 #endif
     default: return hipErrorInvalidValue;
   }
@@ -663,7 +606,7 @@ hipError_t launch_tiled(int variant, bool full, const TiledArgs &args,
 #undef CUKING_PHASED
 }
 
-hipError_t launch_prepare_planes(const uint64_t *d_bit_sets,
+hipError_t launch_prepare_planes(uint32_t layout, const uint64_t *d_bit_sets,
                                  uint32_t words_per_sample,
                                  const PlaneGeometry &geo, uint4 *d_planes,
                                  uint32_t s_tile_begin, uint32_t s_tile_end,
@@ -674,8 +617,12 @@ hipError_t launch_prepare_planes(const uint64_t *d_bit_sets,
   const dim3 grid(s_tile_end - s_tile_begin,
                   (geo.k_words + 2 * kPrepWords - 1) / (2 * kPrepWords));
   if (grid.y == 0) return hipSuccess;
-  prepare_planes_kernel<<<grid, dim3(256), 0, stream>>>(
-      d_bit_sets, words_per_sample, geo, d_planes, s_tile_begin);
+  if (layout == kLayoutQuad)
+    prepare_quads_kernel<<<grid, dim3(256), 0, stream>>>(
+        d_bit_sets, words_per_sample, geo, d_planes, s_tile_begin);
+  else
+    prepare_planes_kernel<<<grid, dim3(256), 0, stream>>>(
+        d_bit_sets, words_per_sample, geo, d_planes, s_tile_begin);
   return hipGetLastError();
 }
 

@@ -18,7 +18,8 @@ from conftest import GOLDEN, random_genotypes
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = [("stream", 0)] + [("tiled", v) for v in range(5)]
+NUM_VARIANTS = 6   # 0-4 VALU shapes, 5 matrix cores (cuking_variant_name)
+KERNELS = [("stream", 0)] + [("tiled", v) for v in range(NUM_VARIANTS)]
 
 
 def select(ctx, kernel, variant, counts_mode=-1):
@@ -137,7 +138,7 @@ def test_thresholded_records_bit_exact(ctx, oracle, kernel, variant, thr):
     assert got.tobytes() == exp.tobytes()   # i, j, kin bits, ibs0/1/2
 
 
-@pytest.mark.parametrize("variant", range(5))
+@pytest.mark.parametrize("variant", range(NUM_VARIANTS))
 @pytest.mark.parametrize("counts_mode", [0, 1])
 @pytest.mark.parametrize("thr", [-1e30, 0.0, 0.1])
 def test_lean_and_full_forms_agree_with_oracle(ctx, oracle, variant, counts_mode, thr):
@@ -158,7 +159,7 @@ def test_lean_and_full_forms_agree_with_oracle(ctx, oracle, variant, counts_mode
     select(ctx, "tiled", 0)
 
 
-@pytest.mark.parametrize("kernel,variant", [("stream", 0), ("tiled", 0), ("tiled", 1)])
+@pytest.mark.parametrize("kernel,variant", [("stream", 0), ("tiled", 0), ("tiled", 1), ("tiled", 5)])
 @pytest.mark.parametrize("k", [2, 3, 4])
 def test_split_factor_shards(ctx, oracle, kernel, variant, k):
     """--split_factor / --shard_index (cuking.cu:46-52): every shard equals the
@@ -187,7 +188,7 @@ def test_split_factor_shards(ctx, oracle, kernel, variant, k):
     assert merged.tobytes() == full.tobytes()
 
 
-@pytest.mark.parametrize("variant", range(5))
+@pytest.mark.parametrize("variant", range(NUM_VARIANTS))
 def test_tile_ranges_union(ctx, oracle, variant):
     """Pair-space sharding for multi-GPU: disjoint tile ranges == whole block."""
     select(ctx, "tiled", variant)
@@ -210,7 +211,7 @@ def test_tile_ranges_union(ctx, oracle, variant):
         ctx.run(sm, bits.shape[1], d_bits, -0.05, tile_range=(0, tiles + 1))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 4])
+@pytest.mark.parametrize("variant", [0, 1, 4, 5])
 @pytest.mark.parametrize("world,chunks", [(1, 1), (1, 4), (2, 3), (3, 8), (8, 5)])
 def test_staged_rectangles_union(ctx, oracle, variant, world, chunks):
     """The overlapped multi-GPU schedule (chunked arrival, row bands, rectangle
@@ -271,7 +272,7 @@ def test_staged_api_errors(ctx, oracle):
                               res, idx[0:1], idx[1:2])
 
 
-@pytest.mark.parametrize("kernel,variant", [("stream", 0), ("tiled", 0)])
+@pytest.mark.parametrize("kernel,variant", [("stream", 0), ("tiled", 0), ("tiled", 5)])
 def test_result_overflow(ctx, oracle, kernel, variant):
     """cuking.cu:297-313, :747-751: overflow is an error, never truncation."""
     import torch
@@ -302,7 +303,7 @@ def test_result_overflow(ctx, oracle, kernel, variant):
     assert got.tobytes() == exp.tobytes()
 
 
-@pytest.mark.parametrize("kernel,variant", [("stream", 0), ("tiled", 0), ("tiled", 2)])
+@pytest.mark.parametrize("kernel,variant", [("stream", 0), ("tiled", 0), ("tiled", 2), ("tiled", 5)])
 def test_long_ranges_are_split_into_several_launches(ctx, oracle, kernel, variant):
     """One launch may not exceed 2^32 - 1 threads (beyond that HIP truncates
     silently): long tile / pair ranges go out as several launches.  The cap is
@@ -506,7 +507,7 @@ def test_c1_kernels_and_variants_agree(ctx, c1):
     n, m, bits = c1["n"], c1["m"], c1["bits"]
     sm = cuking_amd.Submatrix(n)
     base = c1["res"].tobytes()
-    for variant in range(5):
+    for variant in range(NUM_VARIANTS):
         select(ctx, "tiled", variant)
         assert ctx.run(sm, bits.shape[1], bits, 0.05).tobytes() == base, variant
     # the streaming kernel on the whole cohort: 10000 x 2500 workgroups of 256

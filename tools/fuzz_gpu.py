@@ -22,7 +22,7 @@ for case in range(cases):
     n = int(rng.integers(2, 700)); m = int(rng.integers(1, 2500))
     k = int(rng.integers(1, 4)); shard = int(rng.integers(0, k * (k + 1) // 2))
     thr = float(rng.choice([-1e30, -0.2, 0.0, 0.03, 0.0884, 0.3]))
-    variant = int(rng.integers(0, 5)); mode = int(rng.integers(-1, 2))
+    variant = int(rng.integers(0, 6)); mode = int(rng.integers(-1, 2))
     kernel = "stream" if rng.random() < 0.15 else "tiled"
     geno = random_genotypes(rng, n, m, missing=float(rng.choice([0.0, 0.02, 0.3])))
     if n > 3:
