@@ -215,7 +215,7 @@ cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
                 "this bitset has %llu: select variant 0",
                 v.name, kMfmaMaxSites, (unsigned long long)geo.k_words * 32);
 
-  const size_t need = (size_t)geo.k_words * geo.s_stride * sizeof(uint4);
+  const size_t need = plane_bytes(geo, v.layout);
   if (need > ctx->planes_bytes) {
     // Kernels of earlier calls (possibly on other streams) may still read the
     // old workspace: wait for the whole device before replacing it.
@@ -799,7 +799,7 @@ cuking_status cuking_compute_king_rect(
   const TiledVariant &v = tiled_variant(ctx->variant);
   const PlaneGeometry geo = make_geometry(*sm, words_per_sample, v);
   const TileSpace tiles = make_tiles(geo, v, ctx->band_rows);
-  const size_t need = (size_t)geo.k_words * geo.s_stride * sizeof(uint4);
+  const size_t need = plane_bytes(geo, v.layout);
   if (ctx->planes == nullptr || ctx->planes_bytes < need)
     return fail(CUKING_ERR_FAILED_PRECONDITION,
                 "cuking_prepare_samples() has not been called for this block");

@@ -24,14 +24,13 @@ namespace cuking {
 // Padding samples and padding k-words are all-zero (= everything missing),
 // so they add nothing to any sum.
 //
-// Quad layout (kLayoutQuad, the matrix-core kernel): for every quad q of four
-// consecutive 32-site words, plane p and sample s one uint4 holding those four
-// words of ONE plane, planes[(q * 4 + p) * s_stride + s], with the planes
-//     p = 0  A   hom-alt                  (hom_var & ~het)
-//     p = 1  R   hom-ref                  (~het & ~hom_var)
-//     p = 2  H   het and defined          (het & ~hom_var)
-//     p = 3  D   defined                  ~(het & hom_var)
-// Same bytes per sample and site, same padding rules.
+// Quad layout (kLayoutQuad, the matrix-core kernel): the reference's two bit
+// planes as they are, transposed: for every quad q of four consecutive 32-site
+// words, plane p (0 = het, 1 = hom_var, cuking.cu:507-511) and sample s one
+// uint4 holding those four words, planes[(q * 2 + p) * s_stride + s].  Half
+// the bytes of the word layout (2 bits per sample and site); the kernel derives
+// the A / R / H / D fragments with one three-input bit operation each.
+// Padding samples and k-words have both bits set (= missing).
 // ---------------------------------------------------------------------------
 constexpr uint32_t kLayoutWord = 0;
 constexpr uint32_t kLayoutQuad = 1;
@@ -120,6 +119,14 @@ struct TiledArgs {
   const uint64_t *bits;
   uint32_t words_per_sample;
 };
+
+// Bytes of the plane workspace for a geometry.
+__host__ __device__ inline size_t plane_bytes(const PlaneGeometry &g,
+                                              uint32_t layout) {
+  // word layout: 16 B per 32-site word and sample; quad layout: 2 x 16 B per
+  // four words and sample.
+  return (size_t)g.k_words * g.s_stride * (layout == 1 ? 8 : 16);
+}
 
 // One compiled shape of the tiled kernel.
 struct TiledVariant {

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void prepare_planes_kernel(
 }
 
 // Same transpose into the quad layout of the matrix-core kernel: one uint4 =
-// four consecutive 32-site words (two u64 source words) of one plane.
+// four consecutive 32-site words (two u64 source words) of one reference plane.
 __global__ __launch_bounds__(256) void prepare_quads_kernel(
     const uint64_t *__restrict__ bits, uint32_t words_per_sample,
     PlaneGeometry geo, uint4 *__restrict__ planes, uint32_t s_tile_begin) {
@@ -119,26 +119,21 @@ __global__ __launch_bounds__(256) void prepare_quads_kernel(
 
   constexpr int kQuads = kPrepWords / 2;
 #pragma unroll
-  for (int it = 0; it < kQuads * 4 * kPrepSamples / 256; ++it) {
+  for (int it = 0; it < kQuads * 2 * kPrepSamples / 256; ++it) {
     const uint32_t idx = it * 256 + threadIdx.x;
     const uint32_t s = idx % kPrepSamples;
-    const uint32_t p = (idx / kPrepSamples) % 4;
-    const uint32_t ql = idx / (kPrepSamples * 4);
+    const uint32_t p = (idx / kPrepSamples) % 2;
+    const uint32_t ql = idx / (kPrepSamples * 2);
     const uint32_t q = w0 / 2 + ql;
     if (q * 4 >= geo.k_words || s0 + s >= geo.s_stride) continue;
-    uint64_t w[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const uint64_t het = het_lds[s][2 * ql + h], hom = hom_lds[s][2 * ql + h];
-      w[h] = p == 0 ? (hom & ~het) : p == 1 ? ~(het | hom)
-           : p == 2 ? (het & ~hom) : ~(het & hom);
-    }
+    const uint64_t lo = p ? hom_lds[s][2 * ql] : het_lds[s][2 * ql];
+    const uint64_t hi = p ? hom_lds[s][2 * ql + 1] : het_lds[s][2 * ql + 1];
     uint4 v;
-    v.x = (uint32_t)w[0];
-    v.y = (uint32_t)(w[0] >> 32);
-    v.z = (uint32_t)w[1];
-    v.w = (uint32_t)(w[1] >> 32);
-    planes[((uint64_t)q * 4 + p) * geo.s_stride + s0 + s] = v;
+    v.x = (uint32_t)lo;
+    v.y = (uint32_t)(lo >> 32);
+    v.z = (uint32_t)hi;
+    v.w = (uint32_t)(hi >> 32);
+    planes[((uint64_t)q * 2 + p) * geo.s_stride + s0 + s] = v;
   }
 }
 
@@ -551,8 +546,8 @@ const TiledVariant kVariants[kNumTiledVariants] = {
     {"t128_r4x4_k8_w4", 128, 8, 1024, 2 * 2 * 8 * 128 * 16, kLayoutWord},
     {"t64_r4x4_k16_w4", 64, 16, 256, 2 * 2 * 16 * 64 * 16, kLayoutWord},
     // Matrix cores: 128 x 128 pairs per workgroup, 256 sites per k-step,
-    // three 32 KiB LDS stages (king_mfma.hip).
-    {"t128_mfma_fp4", 128, 8, 256, 3 * 2 * 2 * 4 * 128 * 16, kLayoutQuad},
+    // three 16 KiB LDS stages (king_mfma.hip).
+    {"t128_mfma_fp4", 128, 8, 256, 3 * 2 * 2 * 2 * 128 * 16, kLayoutQuad},
 #ifdef CUKING_TUNING
     {"phased_both_barriers", 64, 16, 512, 2 * 2 * 16 * 64 * 16, kLayoutWord},
     {"phased_bar_before_popcount_only", 64, 16, 512, 2 * 2 * 16 * 64 * 16, kLayoutWord},

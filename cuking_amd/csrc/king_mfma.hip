@@ -11,23 +11,26 @@
 // times the bf16 rate; products and sums are small integers, exact in the
 // float32 accumulators while every sum stays below 2^24 (kMfmaMaxSites).
 //
-// Operand expansion costs ONE v_and per dword: a lane's fragment is 32 fp4
-// values = 4 dwords; AND-ing four 32-site words with 0x11111111 << f leaves
-// site 4q+f of each word in nibble q as the fp4 code 1 << f, i.e. the value
-// 2^(f-1) (0.5, 1, 2).  Both operands carry the same factor, and the
-// instruction's E8M0 block scale (2^(1-f) on each side) takes it out again, so
-// every product is exactly 1.0.  f = 3 would be the sign bit: those sites are
-// shifted down to f = 0 first (two ops).  The order of the sites inside the
-// k dimension is irrelevant as long as both operands use the same one.
+// Operand expansion costs ONE VALU instruction per dword.  A lane's fragment
+// is 32 fp4 values = 4 dwords.  From four 32-site words of the reference's two
+// planes (het, hom_var) one v_bitop3_b32 per dword computes e.g.
+// ~het & hom_var & (0x11111111 << f): site 4q+f of each word lands in nibble q
+// as the fp4 code 1 << f, i.e. the value 2^(f-1) (0.5, 1, 2).  Both operands
+// carry the same factor, and the instruction's E8M0 block scale (2^(1-f) on
+// each side) takes it out again, so every product is exactly 1.0 (f = 1 needs
+// no scale and uses the unscaled instruction).  f = 3 would be the sign bit:
+// those sites are shifted down to position 0 first.  The order of the sites
+// inside the k dimension is irrelevant as long as both operands agree.
 //
 // Workgroup = 128 x 128 pairs, 4 wavefronts (one per SIMD, up to 512
 // registers each), each 64 x 64 pairs = 2 x 2 MFMA blocks x 4 (5) float32
 // accumulator sets.  One k-step = 256 sites = for every lane one uint4 (four
 // 32-site words) per plane and block, read from LDS with ds_read_b128 and
 // expanded four times (f = 0..3): 80 (96) MFMAs per k-step and wavefront.
-// The planes come from the quad layout (king_common.h) by LDS-DMA, 32 KiB per
+// The planes come from the quad layout (king_common.h) by LDS-DMA, 16 KiB per
 // k-step, three stages deep.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "king_common.h"
 #include "king_device.h"
@@ -40,46 +43,55 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int kTile = 128;
-constexpr int kStageU4 = 2 * 2 * 4 * kTile;  // sides x k-groups x planes x samples
-constexpr int kPiecesPerWave = 8;            // 32 x 1 KiB per stage, 4 wavefronts
+constexpr int kStageU4 = 2 * 2 * 2 * kTile;  // sides x k-groups x planes x samples
+constexpr int kPiecesPerWave = 4;            // 16 x 1 KiB per stage, 4 wavefronts
 
-// Plane indices of the quad layout.
-constexpr int kA = 0, kR = 1, kH = 2, kD = 3;
+// v_bitop3_b32 truth tables over (het, hom_var, mask), index = 4 het + 2 hom + mask.
+constexpr int kA = 0x08;  // hom-alt:  ~het &  hom & mask
+constexpr int kR = 0x02;  // hom-ref:  ~het & ~hom & mask
+constexpr int kH = 0x20;  // het:       het & ~hom & mask
+constexpr int kD = 0x2A;  // defined:  ~(het & hom) & mask
+constexpr int kY = 0x0A;  // A | R:    ~het & mask
 
-// Fragment f of four 32-site words (see the header comment).
-template <int F>
-__device__ __forceinline__ v8i expand(const uint4 w) {
+// One operand fragment: plane KIND of four 32-site words at nibble position
+// given by `mask` (an SGPR: a 32-bit literal would cost half a cycle more per
+// instruction, tools/micro/mfma_fill).
+template <int KIND>
+__device__ __forceinline__ v8i frag(const uint4 het, const uint4 hom, uint32_t mask) {
   v8i r = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (F < 3) {
-    const uint32_t m = 0x11111111u << F;
-    r[0] = w.x & m; r[1] = w.y & m; r[2] = w.z & m; r[3] = w.w & m;
-  } else {
-    const uint32_t m = 0x11111111u;
-    r[0] = (w.x >> 3) & m; r[1] = (w.y >> 3) & m;
-    r[2] = (w.z >> 3) & m; r[3] = (w.w >> 3) & m;
-  }
+  r[0] = (int)__builtin_amdgcn_bitop3_b32(het.x, hom.x, mask, KIND);
+  r[1] = (int)__builtin_amdgcn_bitop3_b32(het.y, hom.y, mask, KIND);
+  r[2] = (int)__builtin_amdgcn_bitop3_b32(het.z, hom.z, mask, KIND);
+  r[3] = (int)__builtin_amdgcn_bitop3_b32(het.w, hom.w, mask, KIND);
   return r;
 }
 
-__device__ __forceinline__ v8i or_frag(const v8i a, const v8i b) {
-  v8i r = {0, 0, 0, 0, 0, 0, 0, 0};
-  r[0] = a[0] | b[0]; r[1] = a[1] | b[1]; r[2] = a[2] | b[2]; r[3] = a[3] | b[3];
-  return r;
+__device__ __forceinline__ uint4 shr3(const uint4 w) {
+  return make_uint4(w.x >> 3, w.y >> 3, w.z >> 3, w.w >> 3);
 }
 
 // acc += sum over the 64 sites of the fragment of a_site * b_site.  The E8M0
 // scale 2^(1-F) on each side (F == 3 sits at position 0 again) undoes the
-// 2^(F-1) of the expansion.
+// 2^(F-1) of the expansion.  F == 1 needs none: scale operands 0 select the
+// unscaled instruction, which holds the issue port 5 cycles less.
 template <int F>
 __device__ __forceinline__ v16f mma(const v8i a, const v8i b, const v16f c) {
-  constexpr int scale = F == 0 ? 128 : F == 1 ? 127 : F == 2 ? 126 : 128;
+  constexpr int scale = F == 0 ? 128 : F == 1 ? 0 : F == 2 ? 126 : 128;
   return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
       a, b, c, 4 /* A is fp4 */, 4 /* B is fp4 */, 0, scale, 0, scale);
 }
 
-template <int NSTAGE, bool FULL>
+// `n` MFMAs, each followed by `v` VALU instructions (scheduling request).
+#define CUKING_PACE(n, v)                                                      \
+  _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {                         \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                         \
+    if ((v) > 0) __builtin_amdgcn_sched_group_barrier(0x002, (v), 0);          \
+  }
+
+// ABLATE (tuning builds, wrong results): 1 = no LDS-DMA, 2 = no barrier either.
+template <bool FULL, int ABLATE = 0>
 __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
-  static_assert(NSTAGE == 2 || NSTAGE == 3, "two or three LDS stages");
+  constexpr int NSTAGE = 3;
   constexpr int NQ = FULL ? 5 : 4;
   extern __shared__ uint4 lds[];  // [NSTAGE][side][k-group][plane][128]
 
@@ -98,28 +110,43 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   const uint32_t s_stride = a.geo.s_stride;
   const uint32_t num_steps = a.geo.k_words / 8;
 
+  // Requests piece r (1 KiB) of this wavefront's share of k-step
+  // min(step, last) into LDS buffer `buf`.  Clamping keeps the number of DMAs
+  // in flight the same in every iteration, so one counted wait serves the
+  // whole loop; the repeats of the last step land in a buffer nobody reads.
+  auto issue_piece = [&](uint32_t step, uint32_t buf, int r) {
+    if (ABLATE) return;
+    if (step >= num_steps) step = num_steps - 1;
+    const uint32_t piece = wave * kPiecesPerWave + r;  // 0..15
+    const uint32_t side = piece >> 3, kg = (piece >> 2) & 1;
+    const uint32_t p = (piece >> 1) & 1, seg = piece & 1;
+    const uint4 *src = (side ? g_cols : g_rows) +
+                       ((uint64_t)(2 * step + kg) * 2 + p) * s_stride +
+                       seg * 64 + lane;
+    uint4 *dst = lds + buf * kStageU4 + ((side * 2 + kg) * 2 + p) * kTile +
+                 seg * 64;
+    // LDS-DMA, lane l's 16 bytes land at dst + 16 * l.  Inline asm keeps it
+    // out of the compiler's wait-count bookkeeping (king_kernels.hip).
+    const uint32_t lds_addr = (uint32_t)(uintptr_t)(lds_void_ptr)dst;
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off"
+        :
+        : "s"(lds_addr), "v"(src)
+        : "memory");
+  };
   auto issue_stage = [&](uint32_t step, uint32_t buf) {
 #pragma unroll
-    for (int r = 0; r < kPiecesPerWave; ++r) {
-      const uint32_t piece = wave * kPiecesPerWave + r;  // 0..31
-      const uint32_t side = piece >> 4, kg = (piece >> 3) & 1;
-      const uint32_t p = (piece >> 1) & 3, seg = piece & 1;
-      const uint4 *src = (side ? g_cols : g_rows) +
-                         ((uint64_t)(2 * step + kg) * 4 + p) * s_stride +
-                         seg * 64 + lane;
-      uint4 *dst = lds + buf * kStageU4 + ((side * 2 + kg) * 4 + p) * kTile +
-                   seg * 64;
-      // LDS-DMA, lane l's 16 bytes land at dst + 16 * l.  Inline asm keeps it
-      // out of the compiler's wait-count bookkeeping (king_kernels.hip).
-      const uint32_t lds_addr = (uint32_t)(uintptr_t)(lds_void_ptr)dst;
-      asm volatile(
-          "s_mov_b32 m0, %0\n\t"
-          "s_nop 0\n\t"
-          "global_load_lds_dwordx4 %1, off"
-          :
-          : "s"(lds_addr), "v"(src)
-          : "memory");
-    }
+    for (int r = 0; r < kPiecesPerWave; ++r) issue_piece(step, buf, r);
+  };
+  // All but the youngest stage requested so far have landed, for this
+  // wavefront (counted wait) and, after the barrier, for all of them; every
+  // wavefront is also done reading the buffer the next request overwrites.
+  auto stage_sync = [&]() {
+    if (ABLATE == 2) return;
+    __builtin_amdgcn_s_waitcnt(0x0F74);  // vmcnt(4)
+    __syncthreads();
   };
 
   v16f acc[2][2][NQ];
@@ -132,68 +159,172 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[bi][bj][q][r] = 0.f;
 
+  uint32_t m1, m2, m4;  // nibble masks, pinned to SGPRs
+  asm volatile("s_mov_b32 %0, 0x11111111" : "=s"(m1));
+  asm volatile("s_mov_b32 %0, 0x22222222" : "=s"(m2));
+  asm volatile("s_mov_b32 %0, 0x44444444" : "=s"(m4));
+
+  // Raw words of the k-step: [block][plane] for the row and the column side.
+  uint4 A[2][2], B[2][2];
+#define CUKING_LOAD_RAW(BUF)                                                   \
+  {                                                                            \
+    const uint4 *l_rows_ = lds + (BUF) * kStageU4 + (0 * 2 + g) * 2 * kTile + wr + lr; \
+    const uint4 *l_cols_ = lds + (BUF) * kStageU4 + (1 * 2 + g) * 2 * kTile + wc + lr; \
+    _Pragma("unroll") for (int b = 0; b < 2; ++b)                              \
+    _Pragma("unroll") for (int p = 0; p < 2; ++p) {                            \
+      A[b][p] = l_rows_[p * kTile + b * 32];                                   \
+      B[b][p] = l_cols_[p * kTile + b * 32];                                   \
+    }                                                                          \
+  }
+// Fragment set X = planes A, R, H, D of (SA, SB) at the nibble position MASK.
+#define CUKING_EXPAND(X, SA, SB, MASK)                                         \
+  _Pragma("unroll") for (int b = 0; b < 2; ++b) {                              \
+    X##a[b][0] = frag<kA>(SA[b][0], SA[b][1], MASK);                           \
+    X##a[b][1] = frag<kR>(SA[b][0], SA[b][1], MASK);                           \
+    X##a[b][2] = frag<kH>(SA[b][0], SA[b][1], MASK);                           \
+    X##a[b][3] = frag<kD>(SA[b][0], SA[b][1], MASK);                           \
+    X##b[b][0] = frag<kA>(SB[b][0], SB[b][1], MASK);                           \
+    X##b[b][1] = frag<kR>(SB[b][0], SB[b][1], MASK);                           \
+    X##b[b][2] = frag<kH>(SB[b][0], SB[b][1], MASK);                           \
+    X##b[b][3] = frag<kD>(SB[b][0], SB[b][1], MASK);                           \
+  }
+// One plane product (fragment index PA of the rows x PB of the columns) for
+// the four block pairs.
+#define CUKING_MMA1(F, X, PA, PB, Q)                                           \
+  _Pragma("unroll") for (int bi = 0; bi < 2; ++bi)                             \
+  _Pragma("unroll") for (int bj = 0; bj < 2; ++bj)                             \
+    acc[bi][bj][Q] = mma<F>(X##a[bi][PA], X##b[bj][PB], acc[bi][bj][Q]);
+// opp (first half), bh, hi, hj: 16 MFMAs; then the second half of opp.
+#define CUKING_MMA16(F, X)                                                     \
+  CUKING_MMA1(F, X, 0, 1, 0) CUKING_MMA1(F, X, 2, 2, 1)                        \
+  CUKING_MMA1(F, X, 2, 3, 2) CUKING_MMA1(F, X, 3, 2, 3)
+#define CUKING_MMA4(F, X) CUKING_MMA1(F, X, 1, 0, 0)
+
+  issue_stage(0, 0);
+  issue_stage(1, 1);
+  stage_sync();
+
+  if (FULL) {
+    // Five accumulator sets leave no room for a second fragment set: plain
+    // loop, the compiler's order.
+    uint32_t buf = 0;
+    for (uint32_t step = 0; step < num_steps; ++step) {
+      if (step != 0) stage_sync();
+      issue_stage(step + 2, buf == 0 ? 2 : buf - 1);
+      CUKING_LOAD_RAW(buf)
+      uint4 As[2][2], Bs[2][2];
 #pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s)
-    if ((uint32_t)s < num_steps) issue_stage(s, s);
-
-  uint32_t buf = 0;
-  for (uint32_t step = 0; step < num_steps; ++step) {
-    // Stage `step` has landed for this wavefront: at most the NSTAGE - 2
-    // younger stages (8 DMAs each) may still be in flight.
-    if (NSTAGE == 3 && step + 1 < num_steps)
-      __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8)
-    else
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    // ... and for every wavefront, and all of them are done with the buffer
-    // the next request overwrites.
-    __syncthreads();
-    {
-      const uint32_t ahead = step + NSTAGE - 1;
-      uint32_t nbuf = buf + NSTAGE - 1;
-      if (nbuf >= NSTAGE) nbuf -= NSTAGE;
-      if (ahead < num_steps) issue_stage(ahead, nbuf);
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          As[b][p] = shr3(A[b][p]);
+          Bs[b][p] = shr3(B[b][p]);
+        }
+#define CUKING_FULL_STEP(F, SA, SB, MASK)                                      \
+      {                                                                        \
+        v8i Xa[2][4], Xb[2][4];                                                \
+        CUKING_EXPAND(X, SA, SB, MASK)                                         \
+        CUKING_MMA16(F, X)                                                     \
+        CUKING_MMA4(F, X)                                                      \
+        _Pragma("unroll") for (int bi = 0; bi < 2; ++bi)                       \
+        _Pragma("unroll") for (int bj = 0; bj < 2; ++bj)                       \
+          acc[bi][bj][NQ - 1] =                                                \
+              mma<F>(frag<kY>(SA[bi][0], SA[bi][1], MASK),                     \
+                     frag<kY>(SB[bj][0], SB[bj][1], MASK), acc[bi][bj][NQ - 1]); \
+      }
+      CUKING_FULL_STEP(0, A, B, m1)
+      CUKING_FULL_STEP(1, A, B, m2)
+      CUKING_FULL_STEP(2, A, B, m4)
+      CUKING_FULL_STEP(3, As, Bs, m1)
+#undef CUKING_FULL_STEP
+      if (++buf == NSTAGE) buf = 0;
     }
-
-    const uint4 *l_rows = lds + buf * kStageU4 + (0 * 2 + g) * 4 * kTile + wr + lr;
-    const uint4 *l_cols = lds + buf * kStageU4 + (1 * 2 + g) * 4 * kTile + wc + lr;
-    uint4 A[2][4], B[2][4];
+  } else {
+    // Software pipeline: while the MFMAs of fragment f issue, the VALU builds
+    // fragment f + 1 into the other register set (an MFMA never reads a
+    // register written just before it); behind the MFMAs of f = 3 come the
+    // next k-step's stage hand-over, its LDS reads and its f = 0 fragment.
+    // Pacing (tools/micro/mfma_fill): a scaled fp4 MFMA holds the issue port
+    // 13 cycles (unscaled: 8) of its 32, a VALU instruction 4, so 4 (5) hide
+    // behind one MFMA.  The k-step's four LDS-DMA requests go one each into
+    // gaps without VALU work.
+    v8i Xa[2][4], Xb[2][4], Ya[2][4], Yb[2][4];
+    uint4 As[2][2], Bs[2][2];
+    CUKING_LOAD_RAW(0)
+    CUKING_EXPAND(X, A, B, m1)
+    uint32_t buf = 0;  // buffer of the k-step being multiplied
+    for (uint32_t step = 0; step + 1 < num_steps; ++step) {
+      const uint32_t nbuf = buf == NSTAGE - 1 ? 0 : buf + 1;
+      const uint32_t fbuf = buf == 0 ? NSTAGE - 1 : buf - 1;  // free since the last barrier
+      // f = 0 multiplies, f = 1 is built
+      CUKING_EXPAND(Y, A, B, m2)
+      CUKING_MMA16(0, X)
+      CUKING_PACE(16, 4)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        issue_piece(step + 2, fbuf, r);
+        acc[r >> 1][r & 1][0] = mma<0>(Xa[r >> 1][1], Xb[r & 1][0], acc[r >> 1][r & 1][0]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // f = 1 multiplies (unscaled), f = 2 and the shifted words are built
+      CUKING_EXPAND(X, A, B, m4)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          As[b][p] = shr3(A[b][p]);
+          Bs[b][p] = shr3(B[b][p]);
+        }
+      CUKING_MMA16(1, Y)
+      CUKING_MMA4(1, Y)
+      CUKING_PACE(20, 5)
+      __builtin_amdgcn_sched_barrier(0);
+      // f = 2 multiplies, f = 3 is built from the shifted words
+      CUKING_EXPAND(Y, As, Bs, m1)
+      CUKING_MMA16(2, X)
+      CUKING_MMA4(2, X)
+      CUKING_PACE(16, 4) CUKING_PACE(4, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      // f = 3 multiplies; next k-step: hand-over, LDS reads, f = 0
+      stage_sync();
+      CUKING_LOAD_RAW(nbuf)
+      CUKING_EXPAND(X, A, B, m1)
+      CUKING_MMA16(3, Y)
+      CUKING_MMA4(3, Y)
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      CUKING_PACE(4, 0) CUKING_PACE(16, 4)
+      __builtin_amdgcn_sched_barrier(0);
+      buf = nbuf;
+    }
+    // last k-step: nothing left to fetch
+    CUKING_EXPAND(Y, A, B, m2)
+    CUKING_MMA16(0, X)
+    CUKING_MMA4(0, X)
+    CUKING_EXPAND(X, A, B, m4)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        A[b][p] = l_rows[p * kTile + b * 32];
-        B[b][p] = l_cols[p * kTile + b * 32];
+      for (int p = 0; p < 2; ++p) {
+        As[b][p] = shr3(A[b][p]);
+        Bs[b][p] = shr3(B[b][p]);
       }
-
-#define CUKING_MFMA_STEP(F)                                                    \
-    {                                                                          \
-      v8i Af[2][4], Bf[2][4];                                                  \
-      _Pragma("unroll") for (int b = 0; b < 2; ++b)                            \
-      _Pragma("unroll") for (int p = 0; p < 4; ++p) {                          \
-        Af[b][p] = expand<F>(A[b][p]);                                         \
-        Bf[b][p] = expand<F>(B[b][p]);                                         \
-      }                                                                        \
-      _Pragma("unroll") for (int bi = 0; bi < 2; ++bi)                         \
-      _Pragma("unroll") for (int bj = 0; bj < 2; ++bj) {                       \
-        acc[bi][bj][0] = mma<F>(Af[bi][kA], Bf[bj][kR], acc[bi][bj][0]);       \
-        acc[bi][bj][0] = mma<F>(Af[bi][kR], Bf[bj][kA], acc[bi][bj][0]);       \
-        acc[bi][bj][1] = mma<F>(Af[bi][kH], Bf[bj][kH], acc[bi][bj][1]);       \
-        acc[bi][bj][2] = mma<F>(Af[bi][kH], Bf[bj][kD], acc[bi][bj][2]);       \
-        acc[bi][bj][3] = mma<F>(Af[bi][kD], Bf[bj][kH], acc[bi][bj][3]);       \
-        if (FULL)                                                              \
-          acc[bi][bj][NQ - 1] =                                                \
-              mma<F>(or_frag(Af[bi][kA], Af[bi][kR]),                          \
-                     or_frag(Bf[bj][kA], Bf[bj][kR]), acc[bi][bj][NQ - 1]);    \
-      }                                                                        \
-    }
-    CUKING_MFMA_STEP(0)
-    CUKING_MFMA_STEP(1)
-    CUKING_MFMA_STEP(2)
-    CUKING_MFMA_STEP(3)
-#undef CUKING_MFMA_STEP
-
-    if (++buf == NSTAGE) buf = 0;
+    CUKING_MMA16(1, Y)
+    CUKING_MMA4(1, Y)
+    CUKING_EXPAND(Y, As, Bs, m1)
+    CUKING_MMA16(2, X)
+    CUKING_MMA4(2, X)
+    CUKING_MMA16(3, Y)
+    CUKING_MMA4(3, Y)
   }
+  // The clamped repeats of the last stage must have landed before the
+  // workgroup's LDS goes away.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#undef CUKING_LOAD_RAW
+#undef CUKING_EXPAND
+#undef CUKING_MMA1
+#undef CUKING_MMA16
+#undef CUKING_MMA4
 
   // --- epilogue: kinship, threshold, append (cuking.cu:284-313).  C layout of
   // the 32 x 32 MFMA: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
@@ -223,10 +354,10 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   }
 }
 
-template <int NSTAGE, bool FULL>
+template <bool FULL, int ABLATE = 0>
 hipError_t launch_shape(const TiledArgs &args, uint64_t num_tiles,
                         uint32_t lds_bytes, hipStream_t stream) {
-  auto kernel = king_mfma_kernel<NSTAGE, FULL>;
+  auto kernel = king_mfma_kernel<FULL, ABLATE>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(
@@ -254,8 +385,16 @@ hipError_t launch_shape(const TiledArgs &args, uint64_t num_tiles,
 hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
                        uint32_t lds_bytes, hipStream_t stream) {
   if ((uint64_t)args.geo.k_words * 32 > kMfmaMaxSites) return hipErrorInvalidValue;
-  return full ? launch_shape<3, true>(args, num_tiles, lds_bytes, stream)
-              : launch_shape<3, false>(args, num_tiles, lds_bytes, stream);
+#ifdef CUKING_TUNING
+  // Timing-only experiments (wrong results): CUKING_MFMA_ABLATE=1 no LDS-DMA,
+  // =2 no stage barrier either.
+  if (const char *e = getenv("CUKING_MFMA_ABLATE")) {
+    if (e[0] == '1') return launch_shape<false, 1>(args, num_tiles, lds_bytes, stream);
+    if (e[0] == '2') return launch_shape<false, 2>(args, num_tiles, lds_bytes, stream);
+  }
+#endif
+  return full ? launch_shape<true>(args, num_tiles, lds_bytes, stream)
+              : launch_shape<false>(args, num_tiles, lds_bytes, stream);
 }
 
 }  // namespace cuking
