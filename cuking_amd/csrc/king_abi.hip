@@ -112,6 +112,12 @@ struct cuking_ctx {
   size_t band_prefix_entries = 0;
   TileSpace prefix_for = {0, 0, 0, 0};  // tile space the prefix was built for
 
+  // Remainder splitting of the matrix-core kernel (king_mfma.hip): one zeroed
+  // scratch slab per stream that launches it (launches on different streams
+  // may overlap), split_wgs workgroups = one per CU.  0 = never split.
+  uint32_t split_wgs = 0;
+  std::vector<std::pair<hipStream_t, uint32_t *>> split_scratch;
+
   bool timing = false;
   Timer king_timer, prepare_timer;
 };
@@ -177,6 +183,31 @@ uint64_t total_tiles(const TileSpace &t) {
   uint64_t n = 0;
   for (uint32_t b = 0; b < t.num_bands(); ++b) n += t.band_tiles(b);
   return n;
+}
+
+// Split scratch of `stream` (allocated and zeroed on first use), or nullptr
+// when splitting is off / does not apply to the variant.
+cuking_status split_scratch_for(cuking_ctx *ctx, hipStream_t stream,
+                                uint32_t **scratch, uint32_t **counters) {
+  *scratch = *counters = nullptr;
+  if (ctx->split_wgs == 0 || tiled_variant(ctx->variant).layout != kLayoutQuad)
+    return CUKING_OK;
+  const size_t bytes = mfma_split_scratch_bytes(ctx->split_wgs);
+  uint32_t *base = nullptr;
+  for (auto &e : ctx->split_scratch)
+    if (e.first == stream) base = e.second;
+  if (base == nullptr) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base), bytes));
+    hipError_t e = hipMemset(base, 0, bytes);
+    if (e != hipSuccess) {
+      (void)hipFree(base);
+      HIP_TRY(e);
+    }
+    ctx->split_scratch.emplace_back(stream, base);
+  }
+  *counters = base;
+  *scratch = base + ctx->split_wgs;
+  return CUKING_OK;
 }
 
 cuking_status check_block(const cuking_submatrix *sm,
@@ -302,6 +333,10 @@ cuking_status run_tiled(cuking_ctx *ctx, const cuking_submatrix &sm,
   a.rect_row_stride = 1;
   a.bits = d_bit_sets;
   a.words_per_sample = words_per_sample;
+  a.split_tiles = 0;
+  a.split_wgs = ctx->split_wgs;
+  st = split_scratch_for(ctx, stream, &a.split_scratch, &a.split_counters);
+  if (st != CUKING_OK) return st;
 
   EventPair *ev = nullptr;
   if (ctx->timing) HIP_TRY(ctx->king_timer.begin(stream, &ev));
@@ -477,6 +512,7 @@ cuking_status cuking_ctx_create(int device, cuking_ctx **out) {
   cuking_ctx *ctx = new cuking_ctx();
   ctx->device = device;
   ctx->variant = default_variant();
+  ctx->split_wgs = (uint32_t)prop.multiProcessorCount;
   if (const char *v = getenv("CUKING_AMD_BAND_ROWS")) {
     const int k = atoi(v);
     if (k >= 1 && k <= 64) ctx->band_rows = (uint32_t)k;
@@ -490,6 +526,7 @@ void cuking_ctx_destroy(cuking_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->planes) (void)hipFree(ctx->planes);
   if (ctx->band_prefix) (void)hipFree(ctx->band_prefix);
+  for (auto &e : ctx->split_scratch) (void)hipFree(e.second);
   ctx->king_timer.destroy();
   ctx->prepare_timer.destroy();
   delete ctx;
@@ -518,6 +555,18 @@ cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
     if (value < 1 || value > 64)
       return fail(CUKING_ERR_INVALID_ARGUMENT, "band_rows outside [1, 64]");
     ctx->band_rows = (uint32_t)value;
+    return CUKING_OK;
+  }
+  if (strcmp(key, "split_wgs") == 0) {  // 0 = never split the remainder
+    if (value < 0 || value > 4096)
+      return fail(CUKING_ERR_INVALID_ARGUMENT, "split_wgs outside [0, 4096]");
+    if ((uint32_t)value != ctx->split_wgs) {
+      // slabs are sized by the workgroup count
+      HIP_TRY(hipDeviceSynchronize());
+      for (auto &e : ctx->split_scratch) (void)hipFree(e.second);
+      ctx->split_scratch.clear();
+    }
+    ctx->split_wgs = (uint32_t)value;
     return CUKING_OK;
   }
   if (strcmp(key, "max_launch_blocks") == 0) {  // test hook, process-wide
@@ -838,6 +887,10 @@ cuking_status cuking_compute_king_rect(
   a.dense_counts = nullptr;
   a.bits = d_bit_sets;
   a.words_per_sample = words_per_sample;
+  a.split_tiles = 0;
+  a.split_wgs = ctx->split_wgs;
+  st = split_scratch_for(ctx, (hipStream_t)stream, &a.split_scratch, &a.split_counters);
+  if (st != CUKING_OK) return st;
   EventPair *ev = nullptr;
   if (ctx->timing) HIP_TRY(ctx->king_timer.begin((hipStream_t)stream, &ev));
   HIP_TRY(launch_tiled(ctx->variant, use_full_counts(ctx, kin_threshold, false, words_per_sample), a,

@@ -118,6 +118,12 @@ struct TiledArgs {
   // sites from it for the pairs it emits).
   const uint64_t *bits;
   uint32_t words_per_sample;
+  // Matrix-core kernel, remainder launch (king_mfma.hip): split_tiles tiles
+  // from tile_begin are cut into split_wgs equal pieces of k-steps; partial
+  // sums meet in split_scratch (zero between launches), tickets in
+  // split_counters.  split_wgs == 0 or no scratch: never split.
+  uint32_t split_tiles, split_wgs;
+  uint32_t *split_scratch, *split_counters;
 };
 
 // Bytes of the plane workspace for a geometry.
@@ -159,6 +165,8 @@ hipError_t launch_tiled(int variant, bool full, const TiledArgs &args,
 // The matrix-core kernel (king_mfma.hip); reached through launch_tiled.
 hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
                        uint32_t lds_bytes, hipStream_t stream);
+// Bytes of split scratch (slabs + counters) for `wgs` workgroups.
+size_t mfma_split_scratch_bytes(uint32_t wgs);
 
 // Converts plane-sample tiles [s_tile_begin, s_tile_end) (units of 64 plane
 // samples) of the block.

@@ -88,15 +88,32 @@ __device__ __forceinline__ v16f mma(const v8i a, const v8i b, const v16f c) {
     if ((v) > 0) __builtin_amdgcn_sched_group_barrier(0x002, (v), 0);          \
   }
 
+// First work unit of split workgroup w: floor(w * units / wgs).
+__device__ __forceinline__ uint64_t split_bound(uint64_t w, uint64_t units,
+                                                uint32_t wgs) {
+  return w * units / wgs;
+}
+// The split workgroup that owns unit u (needs units >= wgs).
+__device__ __forceinline__ uint32_t split_owner(uint64_t u, uint64_t units,
+                                                uint32_t wgs) {
+  const uint32_t w = (uint32_t)(u * wgs / units);
+  return split_bound(w + 1, units, wgs) <= u ? w + 1 : w;
+}
+
+// SPLIT = false: workgroup = one tile, all k-steps.
+// SPLIT = true ("stream-k" remainder): the launch's tiles x k-steps are one
+// line of work units cut into equal pieces, one per workgroup, so a remainder
+// of tiles that would leave most CUs idle for a whole tile time still fills
+// the chip.  A piece covers the end of one tile and/or the start of the next;
+// partial sums (exact integers) are added into a per-tile scratch slab with
+// agent-scope atomics, and the workgroup that delivers a tile's last part
+// reads the totals back and runs the epilogue.
 // ABLATE (tuning builds, wrong results): 1 = no LDS-DMA, 2 = no barrier either.
-template <bool FULL, int ABLATE = 0>
+template <bool FULL, bool SPLIT, int ABLATE = 0>
 __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   constexpr int NSTAGE = 3;
   constexpr int NQ = FULL ? 5 : 4;
   extern __shared__ uint4 lds[];  // [NSTAGE][side][k-group][plane][128]
-
-  uint32_t tr, tc;
-  if (!decode_tile(a, a.tile_begin + blockIdx.x, &tr, &tc)) return;
 
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -104,11 +121,32 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   const uint32_t wc = (wave & 1) * 64;   // ... and columns
   const uint32_t g = lane >> 5;          // k-group of the MFMA operand
   const uint32_t lr = lane & 31;         // row / column inside the block
+  const uint32_t s_stride = a.geo.s_stride;
+  const uint32_t tile_steps = a.geo.k_words / 8;
+
+  uint32_t m1, m2, m4;  // nibble masks, pinned to SGPRs
+  asm volatile("s_mov_b32 %0, 0x11111111" : "=s"(m1));
+  asm volatile("s_mov_b32 %0, 0x22222222" : "=s"(m2));
+  asm volatile("s_mov_b32 %0, 0x44444444" : "=s"(m4));
+
+  // Work units [unit_lo, unit_hi) of this workgroup; unit = (tile, k-step).
+  const uint64_t units = (uint64_t)a.split_tiles * tile_steps;
+  uint64_t unit_lo = SPLIT ? split_bound(blockIdx.x, units, a.split_wgs)
+                           : (uint64_t)blockIdx.x * tile_steps;
+  const uint64_t unit_hi = SPLIT ? split_bound(blockIdx.x + 1, units, a.split_wgs)
+                                 : unit_lo + tile_steps;
+  while (unit_lo < unit_hi) {
+  const uint32_t seg_tile = (uint32_t)(unit_lo / tile_steps);  // within the launch
+  const uint32_t k_first = (uint32_t)(unit_lo - (uint64_t)seg_tile * tile_steps);
+  const uint32_t num_steps = (unit_hi - unit_lo < (uint64_t)(tile_steps - k_first))
+                                 ? (uint32_t)(unit_hi - unit_lo)
+                                 : tile_steps - k_first;
+  unit_lo += num_steps;
+  uint32_t tr, tc;
+  if (!decode_tile(a, a.tile_begin + seg_tile, &tr, &tc)) continue;  // uniform
 
   const uint4 *g_rows = a.planes + (uint64_t)tr * kTile;
   const uint4 *g_cols = a.planes + a.geo.col_base + (uint64_t)tc * kTile;
-  const uint32_t s_stride = a.geo.s_stride;
-  const uint32_t num_steps = a.geo.k_words / 8;
 
   // Requests piece r (1 KiB) of this wavefront's share of k-step
   // min(step, last) into LDS buffer `buf`.  Clamping keeps the number of DMAs
@@ -117,6 +155,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   auto issue_piece = [&](uint32_t step, uint32_t buf, int r) {
     if (ABLATE) return;
     if (step >= num_steps) step = num_steps - 1;
+    step += k_first;
     const uint32_t piece = wave * kPiecesPerWave + r;  // 0..15
     const uint32_t side = piece >> 3, kg = (piece >> 2) & 1;
     const uint32_t p = (piece >> 1) & 1, seg = piece & 1;
@@ -158,11 +197,6 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[bi][bj][q][r] = 0.f;
-
-  uint32_t m1, m2, m4;  // nibble masks, pinned to SGPRs
-  asm volatile("s_mov_b32 %0, 0x11111111" : "=s"(m1));
-  asm volatile("s_mov_b32 %0, 0x22222222" : "=s"(m2));
-  asm volatile("s_mov_b32 %0, 0x44444444" : "=s"(m4));
 
   // Raw words of the k-step: [block][plane] for the row and the column side.
   uint4 A[2][2], B[2][2];
@@ -320,11 +354,71 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   // The clamped repeats of the last stage must have landed before the
   // workgroup's LDS goes away.
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  if (SPLIT) __syncthreads();  // ... and nobody reads the stages any more
 #undef CUKING_LOAD_RAW
 #undef CUKING_EXPAND
 #undef CUKING_MMA1
 #undef CUKING_MMA16
 #undef CUKING_MMA4
+
+  if (SPLIT && num_steps != tile_steps) {
+    // Partial tile: add this part into the tile's slab, lane-linear
+    // [wave][block pair][sum][register][lane], then take a ticket.
+    uint32_t *slab = a.split_scratch + (size_t)seg_tile * (4 * 4 * NQ * 16 * 64) +
+                     (size_t)wave * (4 * NQ * 16 * 64) + lane;
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            __hip_atomic_fetch_add(
+                slab + (((bi * 2 + bj) * NQ + q) * 16 + r) * 64,
+                (uint32_t)acc[bi][bj][q][r], __ATOMIC_RELAXED,
+                __HIP_MEMORY_SCOPE_AGENT);
+    // Release: every wavefront's adds are performed, then one agent-scope
+    // release fence, then the ticket.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint32_t *flag = reinterpret_cast<uint32_t *>(lds);  // stages are idle now
+    if (threadIdx.x == 0) {
+      // How many workgroups deliver a part of this tile.
+      const uint64_t first_unit = (uint64_t)seg_tile * tile_steps;
+      const uint32_t parts =
+          split_owner(first_unit + tile_steps - 1, units, a.split_wgs) -
+          split_owner(first_unit, units, a.split_wgs) + 1;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const uint32_t ticket = __hip_atomic_fetch_add(
+          a.split_counters + seg_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool last = ticket + 1 == parts;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        a.split_counters[seg_tile] = 0;  // ready for the next launch
+      }
+      *flag = last ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool last = *flag != 0;
+    __syncthreads();  // the flag word is stage memory again after this
+    if (!last) continue;
+    // Totals of all parts; the slab is zeroed again for the next launch.
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            uint32_t *p = slab + (((bi * 2 + bj) * NQ + q) * 16 + r) * 64;
+            acc[bi][bj][q][r] = (float)__builtin_nontemporal_load(p);
+            __builtin_nontemporal_store(0u, p);
+          }
+  }
 
   // --- epilogue: kinship, threshold, append (cuking.cu:284-313).  C layout of
   // the 32 x 32 MFMA: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
@@ -352,12 +446,14 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       }
     }
   }
+  if (SPLIT) __syncthreads();  // LDS is reused by the next piece
+  }  // pieces of this workgroup
 }
 
-template <bool FULL, int ABLATE = 0>
-hipError_t launch_shape(const TiledArgs &args, uint64_t num_tiles,
+template <bool FULL, bool SPLIT, int ABLATE = 0>
+hipError_t launch_shape(const TiledArgs &args, uint64_t num_blocks,
                         uint32_t lds_bytes, hipStream_t stream) {
-  auto kernel = king_mfma_kernel<FULL, ABLATE>;
+  auto kernel = king_mfma_kernel<FULL, SPLIT, ABLATE>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(
@@ -366,10 +462,14 @@ hipError_t launch_shape(const TiledArgs &args, uint64_t num_tiles,
     if (e != hipSuccess) return e;
     attr_set = true;
   }
+  if (SPLIT) {  // one launch of split_wgs workgroups
+    kernel<<<dim3((uint32_t)num_blocks), dim3(256), lds_bytes, stream>>>(args);
+    return hipGetLastError();
+  }
   const uint64_t cap = max_blocks_per_launch(256);
   uint64_t done = 0;
-  while (done < num_tiles) {
-    const uint64_t n = (num_tiles - done < cap) ? num_tiles - done : cap;
+  while (done < num_blocks) {
+    const uint64_t n = (num_blocks - done < cap) ? num_blocks - done : cap;
     TiledArgs a = args;
     a.tile_begin = args.tile_begin + done;
     kernel<<<dim3((uint32_t)n), dim3(256), lds_bytes, stream>>>(a);
@@ -382,6 +482,11 @@ hipError_t launch_shape(const TiledArgs &args, uint64_t num_tiles,
 
 }  // namespace
 
+size_t mfma_split_scratch_bytes(uint32_t wgs) {
+  // wgs - 1 tiles at most, five sums, plus one counter per tile
+  return (size_t)wgs * (4 * 4 * 5 * 16 * 64) * sizeof(uint32_t) + (size_t)wgs * sizeof(uint32_t);
+}
+
 hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
                        uint32_t lds_bytes, hipStream_t stream) {
   if ((uint64_t)args.geo.k_words * 32 > kMfmaMaxSites) return hipErrorInvalidValue;
@@ -389,12 +494,33 @@ hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
   // Timing-only experiments (wrong results): CUKING_MFMA_ABLATE=1 no LDS-DMA,
   // =2 no stage barrier either.
   if (const char *e = getenv("CUKING_MFMA_ABLATE")) {
-    if (e[0] == '1') return launch_shape<false, 1>(args, num_tiles, lds_bytes, stream);
-    if (e[0] == '2') return launch_shape<false, 2>(args, num_tiles, lds_bytes, stream);
+    if (e[0] == '1') return launch_shape<false, false, 1>(args, num_tiles, lds_bytes, stream);
+    if (e[0] == '2') return launch_shape<false, false, 2>(args, num_tiles, lds_bytes, stream);
   }
 #endif
-  return full ? launch_shape<true>(args, num_tiles, lds_bytes, stream)
-              : launch_shape<false>(args, num_tiles, lds_bytes, stream);
+  // Whole rounds of one tile per workgroup, then the remainder cut into equal
+  // pieces over all CUs (needs the scratch slab of the context).
+  const uint32_t wgs = args.split_wgs;
+  const uint32_t tile_steps = args.geo.k_words / 8;
+  uint64_t whole = num_tiles;
+  uint32_t rest = 0;
+  if (wgs != 0 && args.split_scratch != nullptr) {
+    rest = (uint32_t)(num_tiles % wgs);
+    // not worth it when the remainder nearly fills the chip or is tiny
+    if (rest * 8 > wgs * 7 || (uint64_t)rest * tile_steps < 8ull * wgs) rest = 0;
+    whole = num_tiles - rest;
+  }
+  TiledArgs a = args;
+  a.split_tiles = 0;
+  hipError_t e = hipSuccess;
+  if (whole != 0)
+    e = full ? launch_shape<true, false>(a, whole, lds_bytes, stream)
+             : launch_shape<false, false>(a, whole, lds_bytes, stream);
+  if (e != hipSuccess || rest == 0) return e;
+  a.tile_begin = args.tile_begin + whole;
+  a.split_tiles = rest;
+  return full ? launch_shape<true, true>(a, wgs, lds_bytes, stream)
+              : launch_shape<false, true>(a, wgs, lds_bytes, stream);
 }
 
 }  // namespace cuking

@@ -325,6 +325,41 @@ def test_long_ranges_are_split_into_several_launches(ctx, oracle, kernel, varian
         ctx.set_option("max_launch_blocks", 0)
 
 
+@pytest.mark.parametrize("thr,counts_mode", [(0.1, -1), (-1e30, 0), (-1e30, 1)])
+def test_matrix_core_remainder_split(ctx, oracle, thr, counts_mode):
+    """The matrix-core variant cuts a remainder of tiles (fewer than one per CU)
+    into equal pieces of k-steps over all CUs; partial sums meet in a scratch
+    slab.  `split_wgs` stands in for the CU count so that a small block
+    exercises pieces that span tile boundaries, whole tiles and no split."""
+    select(ctx, "tiled", 5, counts_mode)
+    rng = np.random.default_rng(99)
+    n, m = 700, 9000
+    geno = random_genotypes(rng, n, m, missing=0.03)
+    geno[699] = geno[5]
+    geno[300] = geno[128]
+    bits = oracle.bitset_from_genotypes(geno)
+    exp, _, _ = oracle.compute(oracle.submatrix(n), bits, thr)
+    d_bits = ctx.upload_bitset(bits)
+    sm = cuking_amd.Submatrix(n)
+    try:
+        for wgs in (0, 4, 5, 8, 16, 20, 64):
+            ctx.set_option("split_wgs", wgs)
+            for _ in range(2):      # the slab must be clean again after a launch
+                got = ctx.run(sm, bits.shape[1], d_bits, thr)
+                assert got.tobytes() == exp.tobytes(), wgs
+        # a shard (off-diagonal block) and a tile sub-range
+        ctx.set_option("split_wgs", 6)
+        osm = oracle.submatrix(n, 2, 1)
+        bits2 = oracle.bitset_from_genotypes(geno, osm)
+        exp2, _, _ = oracle.compute(osm, bits2, thr)
+        got2 = ctx.run(cuking_amd.Submatrix(n, 2, 1), bits2.shape[1],
+                       ctx.upload_bitset(bits2), thr)
+        assert got2.tobytes() == exp2.tobytes()
+    finally:
+        ctx.set_option("split_wgs", 256)
+        select(ctx, "tiled", 0)
+
+
 def test_appending_calls_share_one_buffer(ctx, oracle):
     """result_index is not reset by the call (cuking.cu:721-722 leaves that to
     the caller), so shards can append into one buffer."""
