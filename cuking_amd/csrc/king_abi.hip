@@ -129,7 +129,18 @@ int default_variant() {
     const int k = atoi(v);
     if (k >= 0 && k < kNumTiledVariants) return k;
   }
-  return 0;
+  return kMfmaVariant;
+}
+
+// The variant that runs for a bitset of this width: the matrix-core variant
+// counts in float32 (exact below 2^24 sites); wider bitsets take the VALU
+// variant with the same tile edge and k padding, so tile indices, tile bounds
+// and prepared ranges mean the same either way.
+int effective_variant(const cuking_ctx *ctx, uint32_t words_per_sample) {
+  if (ctx->variant == kMfmaVariant &&
+      (uint64_t)round_up(words_per_sample, 8) * 32 > kMfmaMaxSites)
+    return 2;
+  return ctx->variant;
 }
 
 // Which form of the tiled kernel.  The lean form saves one v_bcnt per pair and
@@ -190,15 +201,14 @@ uint64_t total_tiles(const TileSpace &t) {
 cuking_status split_scratch_for(cuking_ctx *ctx, hipStream_t stream,
                                 uint32_t **scratch, uint32_t **counters) {
   *scratch = *counters = nullptr;
-  if (ctx->split_wgs == 0 || tiled_variant(ctx->variant).layout != kLayoutQuad)
-    return CUKING_OK;
+  if (ctx->split_wgs == 0 || ctx->variant != kMfmaVariant) return CUKING_OK;
   const size_t bytes = mfma_split_scratch_bytes(ctx->split_wgs);
   uint32_t *base = nullptr;
   for (auto &e : ctx->split_scratch)
     if (e.first == stream) base = e.second;
   if (base == nullptr) {
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base), bytes));
-    hipError_t e = hipMemset(base, 0, bytes);
+    hipError_t e = hipMemset(base, 0, mfma_split_counter_bytes(ctx->split_wgs));
     if (e != hipSuccess) {
       (void)hipFree(base);
       HIP_TRY(e);
@@ -206,7 +216,7 @@ cuking_status split_scratch_for(cuking_ctx *ctx, hipStream_t stream,
     ctx->split_scratch.emplace_back(stream, base);
   }
   *counters = base;
-  *scratch = base + ctx->split_wgs;
+  *scratch = base + mfma_split_counter_bytes(ctx->split_wgs) / sizeof(uint32_t);
   return CUKING_OK;
 }
 
@@ -235,16 +245,11 @@ cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
                       hipStream_t stream, PlaneGeometry *geo_out,
                       TileSpace *tiles_out, uint32_t s_tile_begin = 0,
                       uint32_t s_tile_end = 0xFFFFFFFFu) {
-  const TiledVariant &v = tiled_variant(ctx->variant);
+  const TiledVariant &v = tiled_variant(effective_variant(ctx, words_per_sample));
   const PlaneGeometry geo = make_geometry(sm, words_per_sample, v);
   const TileSpace tiles = make_tiles(geo, v, ctx->band_rows);
   *geo_out = geo;
   *tiles_out = tiles;
-  if (v.layout == kLayoutQuad && (uint64_t)geo.k_words * 32 > kMfmaMaxSites)
-    return fail(CUKING_ERR_FAILED_PRECONDITION,
-                "variant %s counts in float32 and is exact up to %u sites; "
-                "this bitset has %llu: select variant 0",
-                v.name, kMfmaMaxSites, (unsigned long long)geo.k_words * 32);
 
   const size_t need = plane_bytes(geo, v.layout);
   if (need > ctx->planes_bytes) {
@@ -340,7 +345,7 @@ cuking_status run_tiled(cuking_ctx *ctx, const cuking_submatrix &sm,
 
   EventPair *ev = nullptr;
   if (ctx->timing) HIP_TRY(ctx->king_timer.begin(stream, &ev));
-  HIP_TRY(launch_tiled(ctx->variant,
+  HIP_TRY(launch_tiled(effective_variant(ctx, words_per_sample),
                        use_full_counts(ctx, kin_threshold, d_counts != nullptr, words_per_sample), a,
                        tile_end - tile_begin, stream));
   if (ev) HIP_TRY(hipEventRecord(ev->stop, stream));
@@ -513,6 +518,10 @@ cuking_status cuking_ctx_create(int device, cuking_ctx **out) {
   ctx->device = device;
   ctx->variant = default_variant();
   ctx->split_wgs = (uint32_t)prop.multiProcessorCount;
+  if (const char *v = getenv("CUKING_AMD_SPLIT_WGS")) {
+    const int k = atoi(v);
+    if (k >= 0 && k <= 4096) ctx->split_wgs = (uint32_t)k;
+  }
   if (const char *v = getenv("CUKING_AMD_BAND_ROWS")) {
     const int k = atoi(v);
     if (k >= 1 && k <= 64) ctx->band_rows = (uint32_t)k;
@@ -818,7 +827,7 @@ cuking_status cuking_prepare_samples(cuking_ctx *ctx, const cuking_submatrix *sm
   if (!sm_is_diag(*sm))
     return fail(CUKING_ERR_INVALID_ARGUMENT,
                 "staged preparation needs a diagonal block (rows == columns)");
-  const uint32_t tile = tiled_variant(ctx->variant).tile;
+  const uint32_t tile = tiled_variant(effective_variant(ctx, words_per_sample)).tile;
   uint32_t t0, t1;
   st = tile_span(*sm, tile, sample_begin, sample_end, "sample", &t0, &t1);
   if (st != CUKING_OK) return st;
@@ -845,7 +854,7 @@ cuking_status cuking_compute_king_rect(
                 "rectangle launches need a diagonal block (rows == columns)");
   if (!d_result_index || !d_result_overflow || (max_results && !d_results))
     return fail(CUKING_ERR_INVALID_ARGUMENT, "null result pointer");
-  const TiledVariant &v = tiled_variant(ctx->variant);
+  const TiledVariant &v = tiled_variant(effective_variant(ctx, words_per_sample));
   const PlaneGeometry geo = make_geometry(*sm, words_per_sample, v);
   const TileSpace tiles = make_tiles(geo, v, ctx->band_rows);
   const size_t need = plane_bytes(geo, v.layout);
@@ -893,7 +902,8 @@ cuking_status cuking_compute_king_rect(
   if (st != CUKING_OK) return st;
   EventPair *ev = nullptr;
   if (ctx->timing) HIP_TRY(ctx->king_timer.begin((hipStream_t)stream, &ev));
-  HIP_TRY(launch_tiled(ctx->variant, use_full_counts(ctx, kin_threshold, false, words_per_sample), a,
+  HIP_TRY(launch_tiled(effective_variant(ctx, words_per_sample),
+                       use_full_counts(ctx, kin_threshold, false, words_per_sample), a,
                        (uint64_t)n_rows * (c1 - c0), (hipStream_t)stream));
   if (ev) HIP_TRY(hipEventRecord(ev->stop, (hipStream_t)stream));
   return CUKING_OK;

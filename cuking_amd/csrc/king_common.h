@@ -120,8 +120,8 @@ struct TiledArgs {
   uint32_t words_per_sample;
   // Matrix-core kernel, remainder launch (king_mfma.hip): split_tiles tiles
   // from tile_begin are cut into split_wgs equal pieces of k-steps; partial
-  // sums meet in split_scratch (zero between launches), tickets in
-  // split_counters.  split_wgs == 0 or no scratch: never split.
+  // results are parked in split_scratch, tickets in split_counters (zero
+  // between launches).  split_wgs == 0 or no scratch: never split.
   uint32_t split_tiles, split_wgs;
   uint32_t *split_scratch, *split_counters;
 };
@@ -154,6 +154,10 @@ constexpr int kNumTiledVariants = 12;  // + timing-only experiments
 constexpr int kNumTiledVariants = 6;
 #endif
 constexpr int kMfmaVariant = 5;
+#ifndef CUKING_MFMA_STAGES
+#define CUKING_MFMA_STAGES 6
+#endif
+constexpr uint32_t kMfmaLdsBytes = CUKING_MFMA_STAGES * 2 * 2 * 2 * 128 * 16;
 const TiledVariant &tiled_variant(int v);
 // Enqueues tiles [args.tile_begin, args.tile_begin + num_tiles).
 // full = accumulate all five sums for every pair (needed for the diagnostic
@@ -165,8 +169,10 @@ hipError_t launch_tiled(int variant, bool full, const TiledArgs &args,
 // The matrix-core kernel (king_mfma.hip); reached through launch_tiled.
 hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
                        uint32_t lds_bytes, hipStream_t stream);
-// Bytes of split scratch (slabs + counters) for `wgs` workgroups.
+// Bytes of split scratch (counters, then slabs) for `wgs` workgroups, and of
+// the counter part alone (the only part that must start out zero).
 size_t mfma_split_scratch_bytes(uint32_t wgs);
+size_t mfma_split_counter_bytes(uint32_t wgs);
 
 // Converts plane-sample tiles [s_tile_begin, s_tile_end) (units of 64 plane
 // samples) of the block.

@@ -546,8 +546,8 @@ const TiledVariant kVariants[kNumTiledVariants] = {
     {"t128_r4x4_k8_w4", 128, 8, 1024, 2 * 2 * 8 * 128 * 16, kLayoutWord},
     {"t64_r4x4_k16_w4", 64, 16, 256, 2 * 2 * 16 * 64 * 16, kLayoutWord},
     // Matrix cores: 128 x 128 pairs per workgroup, 256 sites per k-step,
-    // three 16 KiB LDS stages (king_mfma.hip).
-    {"t128_mfma_fp4", 128, 8, 256, 3 * 2 * 2 * 2 * 128 * 16, kLayoutQuad},
+    // 16 KiB LDS stages (king_mfma.hip).
+    {"t128_mfma_fp4", 128, 8, 256, kMfmaLdsBytes, kLayoutQuad},
 #ifdef CUKING_TUNING
     {"phased_both_barriers", 64, 16, 512, 2 * 2 * 16 * 64 * 16, kLayoutWord},
     {"phased_bar_before_popcount_only", 64, 16, 512, 2 * 2 * 16 * 64 * 16, kLayoutWord},

@@ -30,10 +30,15 @@
 // The planes come from the quad layout (king_common.h) by LDS-DMA, 16 KiB per
 // k-step, three stages deep.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "king_common.h"
 #include "king_device.h"
+
+#ifndef CUKING_MFMA_STAGES
+#define CUKING_MFMA_STAGES 6
+#endif
 
 namespace cuking {
 
@@ -45,6 +50,14 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 constexpr int kTile = 128;
 constexpr int kStageU4 = 2 * 2 * 2 * kTile;  // sides x k-groups x planes x samples
 constexpr int kPiecesPerWave = 4;            // 16 x 1 KiB per stage, 4 wavefronts
+// LDS stages (16 KiB each): stage s + kStages - 1 is requested while stage s
+// is multiplied, i.e. kStages - 2 k-steps (~1.4 us each) of HBM latency are
+// covered.
+constexpr int kStages = CUKING_MFMA_STAGES;
+// s_waitcnt vmcnt(N) immediate, N = DMAs of the kStages - 2 younger stages.
+constexpr int kYoungerDmas = (kStages - 2) * kPiecesPerWave;
+static_assert(kYoungerDmas < 64, "vmcnt is a 6-bit counter");
+constexpr int kWaitStage = 0x0F70 | (kYoungerDmas & 15) | ((kYoungerDmas >> 4) << 14);
 
 // v_bitop3_b32 truth tables over (het, hom_var, mask), index = 4 het + 2 hom + mask.
 constexpr int kA = 0x08;  // hom-alt:  ~het &  hom & mask
@@ -88,6 +101,10 @@ __device__ __forceinline__ v16f mma(const v8i a, const v8i b, const v16f c) {
     if ((v) > 0) __builtin_amdgcn_sched_group_barrier(0x002, (v), 0);          \
   }
 
+__host__ __device__ inline size_t split_counter_bytes(uint32_t wgs) {
+  return ((size_t)wgs * sizeof(uint32_t) + 255) / 256 * 256;
+}
+
 // First work unit of split workgroup w: floor(w * units / wgs).
 __device__ __forceinline__ uint64_t split_bound(uint64_t w, uint64_t units,
                                                 uint32_t wgs) {
@@ -105,13 +122,13 @@ __device__ __forceinline__ uint32_t split_owner(uint64_t u, uint64_t units,
 // line of work units cut into equal pieces, one per workgroup, so a remainder
 // of tiles that would leave most CUs idle for a whole tile time still fills
 // the chip.  A piece covers the end of one tile and/or the start of the next;
-// partial sums (exact integers) are added into a per-tile scratch slab with
-// agent-scope atomics, and the workgroup that delivers a tile's last part
-// reads the totals back and runs the epilogue.
+// each partial result (exact integers) is parked in a scratch slab, and the
+// workgroup that delivers a tile's last part adds the others to its own and
+// runs the epilogue.
 // ABLATE (tuning builds, wrong results): 1 = no LDS-DMA, 2 = no barrier either.
 template <bool FULL, bool SPLIT, int ABLATE = 0>
 __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
-  constexpr int NSTAGE = 3;
+  constexpr int NSTAGE = kStages;
   constexpr int NQ = FULL ? 5 : 4;
   extern __shared__ uint4 lds[];  // [NSTAGE][side][k-group][plane][128]
 
@@ -121,6 +138,10 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   const uint32_t wc = (wave & 1) * 64;   // ... and columns
   const uint32_t g = lane >> 5;          // k-group of the MFMA operand
   const uint32_t lr = lane & 31;         // row / column inside the block
+  uint32_t lane16 = lane * 16;           // byte offset of the lane in a DMA row
+  // This lane's operand rows inside a stage (uint4 units): rows / columns.
+  uint32_t row_off = (0 * 2 + g) * 2 * kTile + wr + lr;
+  uint32_t col_off = (1 * 2 + g) * 2 * kTile + wc + lr;
   const uint32_t s_stride = a.geo.s_stride;
   const uint32_t tile_steps = a.geo.k_words / 8;
 
@@ -159,9 +180,10 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     const uint32_t piece = wave * kPiecesPerWave + r;  // 0..15
     const uint32_t side = piece >> 3, kg = (piece >> 2) & 1;
     const uint32_t p = (piece >> 1) & 1, seg = piece & 1;
+    // Wave-uniform source row (SGPR pair) + one per-lane byte offset: no
+    // per-request address arithmetic in vector registers.
     const uint4 *src = (side ? g_cols : g_rows) +
-                       ((uint64_t)(2 * step + kg) * 2 + p) * s_stride +
-                       seg * 64 + lane;
+                       ((uint64_t)(2 * step + kg) * 2 + p) * s_stride + seg * 64;
     uint4 *dst = lds + buf * kStageU4 + ((side * 2 + kg) * 2 + p) * kTile +
                  seg * 64;
     // LDS-DMA, lane l's 16 bytes land at dst + 16 * l.  Inline asm keeps it
@@ -170,9 +192,9 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     asm volatile(
         "s_mov_b32 m0, %0\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off"
+        "global_load_lds_dwordx4 %1, %2"
         :
-        : "s"(lds_addr), "v"(src)
+        : "s"(lds_addr), "v"(lane16), "s"(src)
         : "memory");
   };
   auto issue_stage = [&](uint32_t step, uint32_t buf) {
@@ -184,7 +206,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   // wavefront is also done reading the buffer the next request overwrites.
   auto stage_sync = [&]() {
     if (ABLATE == 2) return;
-    __builtin_amdgcn_s_waitcnt(0x0F74);  // vmcnt(4)
+    __builtin_amdgcn_s_waitcnt(kWaitStage);  // vmcnt(kYoungerDmas)
     __syncthreads();
   };
 
@@ -202,8 +224,8 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   uint4 A[2][2], B[2][2];
 #define CUKING_LOAD_RAW(BUF)                                                   \
   {                                                                            \
-    const uint4 *l_rows_ = lds + (BUF) * kStageU4 + (0 * 2 + g) * 2 * kTile + wr + lr; \
-    const uint4 *l_cols_ = lds + (BUF) * kStageU4 + (1 * 2 + g) * 2 * kTile + wc + lr; \
+    const uint4 *l_rows_ = lds + (BUF) * kStageU4 + row_off;                   \
+    const uint4 *l_cols_ = lds + (BUF) * kStageU4 + col_off;                   \
     _Pragma("unroll") for (int b = 0; b < 2; ++b)                              \
     _Pragma("unroll") for (int p = 0; p < 2; ++p) {                            \
       A[b][p] = l_rows_[p * kTile + b * 32];                                   \
@@ -234,17 +256,18 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   CUKING_MMA1(F, X, 2, 3, 2) CUKING_MMA1(F, X, 3, 2, 3)
 #define CUKING_MMA4(F, X) CUKING_MMA1(F, X, 1, 0, 0)
 
-  issue_stage(0, 0);
-  issue_stage(1, 1);
+#pragma unroll
+  for (int st = 0; st < NSTAGE - 1; ++st) issue_stage(st, st);
   stage_sync();
 
   if (FULL) {
     // Five accumulator sets leave no room for a second fragment set: plain
     // loop, the compiler's order.
     uint32_t buf = 0;
+    asm volatile("" : "+v"(row_off), "+v"(col_off), "+v"(lane16));
     for (uint32_t step = 0; step < num_steps; ++step) {
       if (step != 0) stage_sync();
-      issue_stage(step + 2, buf == 0 ? 2 : buf - 1);
+      issue_stage(step + NSTAGE - 1, buf == 0 ? NSTAGE - 1 : buf - 1);
       CUKING_LOAD_RAW(buf)
       uint4 As[2][2], Bs[2][2];
 #pragma unroll
@@ -287,6 +310,10 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     CUKING_LOAD_RAW(0)
     CUKING_EXPAND(X, A, B, m1)
     uint32_t buf = 0;  // buffer of the k-step being multiplied
+    // The loop's per-lane invariants sit in registers from here on: a spill
+    // reload whose first use is inside the loop would put the compiler's
+    // s_waitcnt vmcnt(0) there, draining the DMA pipeline in every iteration.
+    asm volatile("" : "+v"(row_off), "+v"(col_off), "+v"(lane16));
     for (uint32_t step = 0; step + 1 < num_steps; ++step) {
       const uint32_t nbuf = buf == NSTAGE - 1 ? 0 : buf + 1;
       const uint32_t fbuf = buf == 0 ? NSTAGE - 1 : buf - 1;  // free since the last barrier
@@ -297,7 +324,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        issue_piece(step + 2, fbuf, r);
+        issue_piece(step + NSTAGE - 1, fbuf, r);
         acc[r >> 1][r & 1][0] = mma<0>(Xa[r >> 1][1], Xb[r & 1][0], acc[r >> 1][r & 1][0]);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -362,38 +389,52 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
 #undef CUKING_MMA4
 
   if (SPLIT && num_steps != tile_steps) {
-    // Partial tile: add this part into the tile's slab, lane-linear
-    // [wave][block pair][sum][register][lane], then take a ticket.
-    uint32_t *slab = a.split_scratch + (size_t)seg_tile * (4 * 4 * NQ * 16 * 64) +
-                     (size_t)wave * (4 * NQ * 16 * 64) + lane;
+    // Partial tile: park this part in its own slab (plain 16-byte stores,
+    // lane-linear [wave][block pair][sum][4 registers][lane]), then take a
+    // ticket of the tile.  Slab of a part: 2 * workgroup + (0 for the piece in
+    // the workgroup's first tile, 1 for the piece in its second).
+    constexpr size_t kSlabU4 = 4 * 4 * NQ * 4 * 64;  // uint4 per slab
+    const uint64_t first_unit = (uint64_t)seg_tile * tile_steps;
+    const uint64_t my_first = split_bound(blockIdx.x, units, a.split_wgs);
+    const uint32_t my_slab = 2 * blockIdx.x + (my_first / tile_steps == seg_tile ? 0 : 1);
+    float4 *slabs = reinterpret_cast<float4 *>(a.split_scratch);
+    {
+      // Write-through (sc1) 16-byte stores: the data is in memory when the
+      // wait below returns, so no release fence (which would write back the
+      // whole L2: tens of microseconds with 256 KiB freshly dirtied).
+      typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          slabs + my_slab * kSlabU4, 0, (int)(kSlabU4 * 16), 0x00020000);
+      const int base = (int)((wave * (4 * NQ * 4 * 64) + lane) * 16);
 #pragma unroll
-    for (int bi = 0; bi < 2; ++bi)
+      for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
-      for (int bj = 0; bj < 2; ++bj)
+        for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
+          for (int q = 0; q < NQ; ++q)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            __hip_atomic_fetch_add(
-                slab + (((bi * 2 + bj) * NQ + q) * 16 + r) * 64,
-                (uint32_t)acc[bi][bj][q][r], __ATOMIC_RELAXED,
-                __HIP_MEMORY_SCOPE_AGENT);
-    // Release: every wavefront's adds are performed, then one agent-scope
-    // release fence, then the ticket.
+            for (int r4 = 0; r4 < 4; ++r4) {
+              v4u v;
+              v[0] = __float_as_uint(acc[bi][bj][q][4 * r4]);
+              v[1] = __float_as_uint(acc[bi][bj][q][4 * r4 + 1]);
+              v[2] = __float_as_uint(acc[bi][bj][q][4 * r4 + 2]);
+              v[3] = __float_as_uint(acc[bi][bj][q][4 * r4 + 3]);
+              __builtin_amdgcn_raw_buffer_store_b128(
+                  v, rsrc, base + ((((bi * 2 + bj) * NQ + q) * 4 + r4) * 64) * 16, 0,
+                  16 /* sc1 */);
+            }
+    }
+    // Every wavefront's stores are done (and written through), then the
+    // ticket (cdna_hip_programming.md, Guideline 16: sc1 payload + counter).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     uint32_t *flag = reinterpret_cast<uint32_t *>(lds);  // stages are idle now
+    const uint32_t w_first = split_owner(first_unit, units, a.split_wgs);
+    const uint32_t w_last = split_owner(first_unit + tile_steps - 1, units, a.split_wgs);
     if (threadIdx.x == 0) {
-      // How many workgroups deliver a part of this tile.
-      const uint64_t first_unit = (uint64_t)seg_tile * tile_steps;
-      const uint32_t parts =
-          split_owner(first_unit + tile_steps - 1, units, a.split_wgs) -
-          split_owner(first_unit, units, a.split_wgs) + 1;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const uint32_t ticket = __hip_atomic_fetch_add(
           a.split_counters + seg_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const bool last = ticket + 1 == parts;
+      const bool last = ticket == w_last - w_first;
       if (last) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -405,19 +446,27 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     const bool last = *flag != 0;
     __syncthreads();  // the flag word is stage memory again after this
     if (!last) continue;
-    // Totals of all parts; the slab is zeroed again for the next launch.
+    // Totals: this part is still in registers, the others come from their slabs.
+    for (uint32_t w = w_first; w <= w_last; ++w) {
+      if (w == blockIdx.x) continue;
+      const uint32_t slab =
+          2 * w + (split_bound(w, units, a.split_wgs) / tile_steps == seg_tile ? 0 : 1);
+      const float4 *src = slabs + slab * kSlabU4 + (size_t)wave * (4 * NQ * 4 * 64) + lane;
 #pragma unroll
-    for (int bi = 0; bi < 2; ++bi)
+      for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
-      for (int bj = 0; bj < 2; ++bj)
+        for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
+          for (int q = 0; q < NQ; ++q)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            uint32_t *p = slab + (((bi * 2 + bj) * NQ + q) * 16 + r) * 64;
-            acc[bi][bj][q][r] = (float)__builtin_nontemporal_load(p);
-            __builtin_nontemporal_store(0u, p);
-          }
+            for (int r4 = 0; r4 < 4; ++r4) {
+              const float4 v = src[(((bi * 2 + bj) * NQ + q) * 4 + r4) * 64];
+              acc[bi][bj][q][4 * r4] += v.x;
+              acc[bi][bj][q][4 * r4 + 1] += v.y;
+              acc[bi][bj][q][4 * r4 + 2] += v.z;
+              acc[bi][bj][q][4 * r4 + 3] += v.w;
+            }
+    }
   }
 
   // --- epilogue: kinship, threshold, append (cuking.cu:284-313).  C layout of
@@ -483,9 +532,11 @@ hipError_t launch_shape(const TiledArgs &args, uint64_t num_blocks,
 }  // namespace
 
 size_t mfma_split_scratch_bytes(uint32_t wgs) {
-  // wgs - 1 tiles at most, five sums, plus one counter per tile
-  return (size_t)wgs * (4 * 4 * 5 * 16 * 64) * sizeof(uint32_t) + (size_t)wgs * sizeof(uint32_t);
+  // one counter per tile (padded to 16 bytes), then two slabs of five sums per
+  // workgroup
+  return split_counter_bytes(wgs) + (size_t)wgs * 2 * (4 * 4 * 5 * 16 * 64) * sizeof(float);
 }
+size_t mfma_split_counter_bytes(uint32_t wgs) { return split_counter_bytes(wgs); }
 
 hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
                        uint32_t lds_bytes, hipStream_t stream) {
@@ -498,18 +549,27 @@ hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
     if (e[0] == '2') return launch_shape<false, false, 2>(args, num_tiles, lds_bytes, stream);
   }
 #endif
-  // Whole rounds of one tile per workgroup, then the remainder cut into equal
-  // pieces over all CUs (needs the scratch slab of the context).
+  // Short launches (a few tiles per CU or fewer: small blocks, the rectangles
+  // of the staged multi-GPU schedule) run whole rounds of one tile per
+  // workgroup and then the remainder cut into equal pieces over all CUs
+  // (measured: 36 tiles 0.57 -> 0.25 ms, 820 tiles 2.40 -> 2.20 ms).  With
+  // many rounds the dispatcher's own back-filling does as well and the second
+  // launch's boundary costs more than it saves (3160 tiles: +1 %), so long
+  // launches stay whole.
   const uint32_t wgs = args.split_wgs;
   const uint32_t tile_steps = args.geo.k_words / 8;
   uint64_t whole = num_tiles;
   uint32_t rest = 0;
-  if (wgs != 0 && args.split_scratch != nullptr) {
+  if (wgs != 0 && args.split_scratch != nullptr && num_tiles < 8ull * wgs) {
     rest = (uint32_t)(num_tiles % wgs);
     // not worth it when the remainder nearly fills the chip or is tiny
     if (rest * 8 > wgs * 7 || (uint64_t)rest * tile_steps < 8ull * wgs) rest = 0;
     whole = num_tiles - rest;
   }
+  if (getenv("CUKING_AMD_DEBUG"))
+    fprintf(stderr, "launch_mfma: tiles %llu whole %llu rest %u wgs %u scratch %p\n",
+            (unsigned long long)num_tiles, (unsigned long long)whole, rest, wgs,
+            (void *)args.split_scratch);
   TiledArgs a = args;
   a.split_tiles = 0;
   hipError_t e = hipSuccess;

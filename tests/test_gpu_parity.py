@@ -360,6 +360,34 @@ def test_matrix_core_remainder_split(ctx, oracle, thr, counts_mode):
         select(ctx, "tiled", 0)
 
 
+@pytest.mark.parametrize("sites,expect_fallback", [((1 << 24) - 256, False), ((1 << 24) + 512, True)])
+def test_matrix_core_float_limit(ctx, oracle, sites, expect_fallback):
+    """The matrix-core variant counts in float32: exact while every sum stays
+    below 2^24.  Just under the limit with sums as large as they get (every
+    site het in every sample) it must still be bit-exact; just over it the
+    library switches to the VALU variant with the same tile geometry."""
+    select(ctx, "tiled", 5)
+    n = 20
+    wps = cuking_amd.words_per_sample(sites)
+    rng = np.random.default_rng(3)
+    bits = np.zeros((n, wps), dtype=np.uint64)
+    bits[:, : wps // 2] = ~np.uint64(0)                 # het plane: all het ...
+    bits[:6, wps // 2:] = rng.integers(0, 1 << 63, size=(6, wps // 2), dtype=np.uint64)  # ... some missing
+    bits[12] = rng.integers(0, 1 << 63, size=wps, dtype=np.uint64)
+    bits[13] = bits[12]
+    pad = wps // 2 * 64 - sites                          # padding sites stay missing
+    if pad:
+        tail = np.uint64((~np.uint64(0)) << np.uint64(64 - pad))
+        bits[:, wps - 1] |= tail
+        bits[:, wps // 2 - 1] |= tail
+    osm = oracle.submatrix(n)
+    exp, _, _ = oracle.compute(osm, bits, -1e30, threads=8)
+    got = ctx.run(cuking_amd.Submatrix(n), wps, ctx.upload_bitset(bits), -1e30)
+    assert got.tobytes() == exp.tobytes()
+    assert int(exp["ibs2"].max()) + int(exp["ibs1"].max()) > (1 << 23)
+    select(ctx, "tiled", 0)
+
+
 def test_appending_calls_share_one_buffer(ctx, oracle):
     """result_index is not reset by the call (cuking.cu:721-722 leaves that to
     the caller), so shards can append into one buffer."""
