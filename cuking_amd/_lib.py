@@ -71,6 +71,7 @@ SIGNATURES = {
                                   _vp, _vp]),
     "cuking_ctx_set_kernel": (_int, [_vp, _int]),
     "cuking_ctx_set_option": (_int, [_vp, C.c_char_p, _i64]),
+    "cuking_ctx_get_option": (_int, [_vp, C.c_char_p, C.POINTER(_i64)]),
     "cuking_num_variants": (_int, []),
     "cuking_variant_name": (C.c_char_p, [_int]),
     "cuking_compute_king": (_int, [_vp, _SM, _u32, _vp, _f32, _u32, _vp, _vp,

@@ -166,6 +166,15 @@ class KingContext:
     def set_option(self, key: str, value: int) -> None:
         check(self.lib.cuking_ctx_set_option(self.handle, key.encode(), value))
 
+    def get_option(self, key: str) -> int:
+        value = C.c_int64(0)
+        check(self.lib.cuking_ctx_get_option(self.handle, key.encode(), C.byref(value)))
+        return int(value.value)
+
+    def variant_name(self, variant: int | None = None) -> str:
+        v = self.get_option("variant") if variant is None else variant
+        return self.lib.cuking_variant_name(v).decode()
+
     def num_tiles(self, sm: Submatrix) -> int:
         return self.lib.cuking_num_tiles(self.handle, C.byref(sm.c))
 

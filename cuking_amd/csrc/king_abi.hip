@@ -738,6 +738,18 @@ cuking_status cuking_tile_bounds(const cuking_ctx *ctx,
   return CUKING_OK;
 }
 
+cuking_status cuking_ctx_get_option(const cuking_ctx *ctx, const char *key,
+                                    int64_t *value) {
+  if (ctx == nullptr || key == nullptr || value == nullptr)
+    return fail(CUKING_ERR_INVALID_ARGUMENT, "null argument");
+  if (strcmp(key, "variant") == 0) *value = ctx->variant;
+  else if (strcmp(key, "split_wgs") == 0) *value = ctx->split_wgs;
+  else if (strcmp(key, "band_rows") == 0) *value = ctx->band_rows;
+  else if (strcmp(key, "counts_mode") == 0) *value = ctx->counts_mode;
+  else return fail(CUKING_ERR_INVALID_ARGUMENT, "unknown option %s", key);
+  return CUKING_OK;
+}
+
 int cuking_num_variants(void) { return kNumTiledVariants; }
 const char *cuking_variant_name(int variant) {
   if (variant < 0 || variant >= kNumTiledVariants) return "";

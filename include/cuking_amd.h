@@ -149,8 +149,11 @@ typedef enum cuking_kernel {
   CUKING_KERNEL_STREAM = 1  /* one pair per wavefront, wave-level reductions */
 } cuking_kernel;
 cuking_status cuking_ctx_set_kernel(cuking_ctx *ctx, cuking_kernel kernel);
-/* Tuning knobs of the tiled kernel: "variant" (compiled tile shape, 0 ..
- * cuking_num_variants()-1; also env CUKING_AMD_VARIANT), "band_rows"
+/* Tuning knobs of the tiled kernel: "variant" (compiled kernel shape, 0 ..
+ * cuking_num_variants()-1; also env CUKING_AMD_VARIANT; the default is the
+ * matrix-core variant, 0..4 are VALU AND/popcount shapes), "split_wgs"
+ * (matrix-core variant: short launches cut their remainder of tiles into this
+ * many equal pieces, default one per CU, 0 = never), "band_rows"
  * (tile-rows per scheduling band, 1..64; env CUKING_AMD_BAND_ROWS) and
  * "counts_mode" (0 = lean: four sums per pair in the main loop, the hom/hom
  * count behind IBS2 recounted only for emitted pairs; 1 = full: all five sums
@@ -159,6 +162,9 @@ cuking_status cuking_ctx_set_kernel(cuking_ctx *ctx, cuking_kernel kernel);
  * not depend on any of them. */
 cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
                                     int64_t value);
+/* Current value of "variant", "split_wgs", "band_rows" or "counts_mode". */
+cuking_status cuking_ctx_get_option(const cuking_ctx *ctx, const char *key,
+                                    int64_t *value);
 int cuking_num_variants(void);
 const char *cuking_variant_name(int variant);
 
