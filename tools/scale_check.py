@@ -6,8 +6,9 @@ through sub-blocks re-computed by the oracle and size-independent properties.
   c2    BASELINE configs[2]: 100k samples x 100k sites, whole triangle
         (4,999,950,000 pairs), threshold 0.0884 (the default, cuking.cu:43)
   c4    BASELINE configs[4] geometry: 734k samples x 200k sites on ONE GPU
-        (36.7 GB bitset + 73 GB kernel layout): the last tile range only, which
-        exercises > 2^32-element indexing; sub-blocks vs oracle
+        (36.7 GB bitset + as much again for the kernel layout): the last tile
+        range, which exercises > 2^32-element indexing, sub-blocks vs oracle;
+        with --whole also the entire 2.7e11-pair triangle in one call
 """
 import argparse
 import json
@@ -45,6 +46,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("which", choices=["c2", "c4"])
     ap.add_argument("--out", default=str(ROOT / "gpurun_out" / "scale_check.jsonl"))
+    ap.add_argument("--whole", action="store_true", help="c4: also run every pair")
     args = ap.parse_args()
     import torch
     import cuking_amd
@@ -77,6 +79,7 @@ def main():
         dt = time.perf_counter() - t0
         tm = ctx.timing_collect()
         pairs = sm.NumPairs()
+        report["variant"] = ctx.variant_name()
         report.update(pairs=pairs, wall_s=dt, king_ms=tm.king_ms, prepare_ms=tm.prepare_ms,
                       pairs_per_s=pairs / (tm.king_ms * 1e-3), results=int(len(res)))
         print(f"[c2] {pairs} pairs: kernel {tm.king_ms:.1f} ms, prepare {tm.prepare_ms:.1f} ms, "
@@ -98,7 +101,9 @@ def main():
         report["variant1_identical"] = True
     else:
         tiles = ctx.num_tiles(sm)
+        tile = ctx.tile_samples()
         report["tiles"] = tiles
+        report["variant"] = ctx.variant_name()
         take = 150_000
         # (1) the LAST tiles of the enumeration: largest sample indices,
         #     offsets beyond 2^32 uint4 elements in the kernel layout
@@ -110,7 +115,8 @@ def main():
         print(f"[c4] last {take} of {tiles} tiles: kernel {tm.king_ms:.1f} ms, prepare "
               f"{tm.prepare_ms:.1f} ms, wall {dt:.1f}s, {len(res_hi)} records", flush=True)
         report.update(last_tiles=take, king_ms=tm.king_ms, prepare_ms=tm.prepare_ms,
-                      pairs_per_s=take * 4096 / (tm.king_ms * 1e-3), results_hi=int(len(res_hi)))
+                      pairs_per_s=take * tile * tile / (tm.king_ms * 1e-3),
+                      results_hi=int(len(res_hi)))
         lib = ctx.lib
         import ctypes as C
         rb, re_, cb, ce = (C.c_uint32() for _ in range(4))
@@ -126,7 +132,7 @@ def main():
         report["pairs_rechecked_by_oracle"] = seen
         # (2) the staged rectangle path on the far corner
         import torch as _t
-        lo = (n // 64 - 40) * 64
+        lo = (n // tile - 20) * tile
         results = _t.zeros((1 << 20, 6), dtype=_t.int32, device="cuda:0")
         idx = _t.zeros(2, dtype=_t.int32, device="cuda:0")
         ctx.prepare_samples(sm, wps, bits, lo, n)
@@ -144,6 +150,25 @@ def main():
         assert recs.tobytes() == exp.tobytes()
         report["corner_rect_pairs"] = (n - lo) * (n - lo - 1) // 2
         report["corner_rect_records"] = int(len(exp))
+        if args.whole:
+            # (3) every pair of the cohort in one call
+            ctx.timing_reset()
+            t0 = time.perf_counter()
+            res = ctx.run(sm, wps, bits, thr, max_results=8 << 20)
+            dt = time.perf_counter() - t0
+            tm = ctx.timing_collect()
+            pairs = sm.NumPairs()
+            print(f"[c4] whole triangle, {pairs} pairs: kernel {tm.king_ms / 1e3:.1f} s, "
+                  f"prepare {tm.prepare_ms:.1f} ms, {pairs / (tm.king_ms * 1e-3):.3e} pairs/s, "
+                  f"{len(res)} records", flush=True)
+            got = {(int(r["sample_i"]), int(r["sample_j"])) for r in res}
+            want = {(min(a, b), max(a, b)) for a, b, rel in cohort.planted}
+            assert want <= got, f"{len(want - got)} planted relatives missing"
+            hi = res[(res["sample_i"] >= lo) & (res["sample_j"] >= lo)]
+            assert hi.tobytes() == exp.tobytes()      # far corner again, from the whole run
+            report.update(whole_pairs=pairs, whole_king_s=tm.king_ms / 1e3, whole_wall_s=dt,
+                          whole_pairs_per_s=pairs / (tm.king_ms * 1e-3),
+                          whole_records=int(len(res)))
     report["ok"] = True
     print(json.dumps(report), flush=True)
     with open(args.out, "a") as f:
