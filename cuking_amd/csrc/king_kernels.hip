@@ -2,16 +2,18 @@
 //
 //   prepare_planes_kernel  reference bitset (cuking.cu:507-523) -> k-major
 //                          4-plane layout (king_common.h)
-//   king_tiled_kernel      the throughput kernel: LDS-staged, register-tiled
+//   prepare_quads_kernel   ... -> quad layout of the matrix-core kernel
+//   king_tiled_kernel      the VALU pair kernel: LDS-staged, register-tiled
 //                          AND+popcount over all pairs of a tile, issued as
 //                          barrier-aligned logic / popcount phases
-//                          (replaces ComputeKingKernel, cuking.cu:191-314)
+//                          (ComputeKingKernel, cuking.cu:191-314; variants
+//                          0-4 -- the default is king_mfma.hip, variant 5)
 //   king_stream_kernel     one pair per wavefront straight from the reference
 //                          layout, wave-level reductions (same contract)
 //   pack_kernel            cuking.cu:675-703 on the device
 //
-// No MFMA: the work is AND / BITOP3 / BCNT on 32-bit words (VALU) fed from
-// LDS; see DESIGN.md for the op count and the rooflines.
+// In this file the work is AND / BITOP3 / BCNT on 32-bit words (VALU) fed
+// from LDS; see DESIGN.md for the op count and the rooflines.
 #include <hip/hip_runtime.h>
 
 #include "king_common.h"

@@ -145,7 +145,7 @@ cuking_status cuking_pack_device(cuking_ctx *ctx, const cuking_submatrix *sm,
 
 /* Which device kernel evaluates the pairs. */
 typedef enum cuking_kernel {
-  CUKING_KERNEL_TILED = 0,  /* LDS-staged, register-tiled popcount kernel (default) */
+  CUKING_KERNEL_TILED = 0,  /* LDS-staged tile kernels: matrix-core variant (default) or VALU popcount variants */
   CUKING_KERNEL_STREAM = 1  /* one pair per wavefront, wave-level reductions */
 } cuking_kernel;
 cuking_status cuking_ctx_set_kernel(cuking_ctx *ctx, cuking_kernel kernel);
