@@ -60,6 +60,9 @@ def build_library(force: bool = False, save_temps: bool = False,
            *map(str, srcs), "-o", str(LIB_PATH)]
     if tuning:
         cmd.insert(1, "-DCUKING_TUNING")
+    # experiments: extra -D flags, e.g. CUKING_EXTRA_HIPFLAGS="-DCUKING_MFMA_STAGES=3"
+    for flag in os.environ.get("CUKING_EXTRA_HIPFLAGS", "").split():
+        cmd.insert(1, flag)
     cwd = PKG
     if save_temps:  # keeps the .s / resource-usage remarks for inspection
         cwd = PKG / "build_tmp"
