@@ -432,13 +432,15 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     const uint32_t w_first = split_owner(first_unit, units, a.split_wgs);
     const uint32_t w_last = split_owner(first_unit + tile_steps - 1, units, a.split_wgs);
     if (threadIdx.x == 0) {
+      // One counter per workgroup: a workgroup owns the first unit of at most
+      // one tile that continues into the next workgroup.
       const uint32_t ticket = __hip_atomic_fetch_add(
-          a.split_counters + seg_tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          a.split_counters + w_first, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const bool last = ticket == w_last - w_first;
       if (last) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        a.split_counters[seg_tile] = 0;  // ready for the next launch
+        a.split_counters[w_first] = 0;  // ready for the next launch
       }
       *flag = last ? 1u : 0u;
     }
@@ -552,7 +554,8 @@ hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
   // Short launches (a few tiles per CU or fewer: small blocks, the rectangles
   // of the staged multi-GPU schedule) run whole rounds of one tile per
   // workgroup and then the remainder cut into equal pieces over all CUs
-  // (measured: 36 tiles 0.57 -> 0.25 ms, 820 tiles 2.40 -> 2.20 ms).  With
+  // (measured: 36 tiles 0.57 -> 0.25 ms, 820 tiles 2.40 -> 2.20 ms); under two
+  // tiles per CU the whole launch goes out as pieces.  With
   // many rounds the dispatcher's own back-filling does as well and the second
   // launch's boundary costs more than it saves (3160 tiles: +1 %), so long
   // launches stay whole.
@@ -561,11 +564,27 @@ hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
   uint64_t whole = num_tiles;
   uint32_t rest = 0;
   if (wgs != 0 && args.split_scratch != nullptr && num_tiles < 8ull * wgs) {
-    rest = (uint32_t)(num_tiles % wgs);
-    // not worth it when the remainder nearly fills the chip or is tiny
-    if (rest * 8 > wgs * 7 || (uint64_t)rest * tile_steps < 8ull * wgs) rest = 0;
+    if (num_tiles < 2ull * wgs) {
+      // under two tiles per CU: everything as pieces (300 tiles: 0.98 -> 0.91 ms)
+      rest = (uint32_t)num_tiles;
+    } else {
+      rest = (uint32_t)(num_tiles % wgs);
+      // not worth it when the remainder nearly fills the chip
+      if (rest * 8 > wgs * 7) rest = 0;
+    }
+    if ((uint64_t)rest * tile_steps < 8ull * wgs) rest = 0;  // too little work to cut up
     whole = num_tiles - rest;
   }
+#ifdef CUKING_TUNING
+  // experiment: every launch as one persistent stream-k launch (20k samples:
+  // 26.2 -> 29.9 ms, the contiguous tile ranges lose the L2 sharing of the
+  // band order)
+  if (getenv("CUKING_MFMA_SPLIT_ALL") && wgs != 0 && args.split_scratch != nullptr &&
+      num_tiles < 0xFFFFFFFFull && num_tiles * tile_steps >= 8ull * wgs) {
+    rest = (uint32_t)num_tiles;
+    whole = 0;
+  }
+#endif
   if (getenv("CUKING_AMD_DEBUG"))
     fprintf(stderr, "launch_mfma: tiles %llu whole %llu rest %u wgs %u scratch %p\n",
             (unsigned long long)num_tiles, (unsigned long long)whole, rest, wgs,
