@@ -207,8 +207,18 @@ cuking_status split_scratch_for(cuking_ctx *ctx, hipStream_t stream,
   for (auto &e : ctx->split_scratch)
     if (e.first == stream) base = e.second;
   if (base == nullptr) {
+    if (ctx->split_scratch.size() >= 8) {
+      // Streams come and go (torch hands out new handles): keep the cache
+      // small.  Nothing may still be using a slab we free.
+      HIP_TRY(hipDeviceSynchronize());
+      for (auto &e : ctx->split_scratch) (void)hipFree(e.second);
+      ctx->split_scratch.clear();
+    }
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base), bytes));
-    hipError_t e = hipMemset(base, 0, mfma_split_counter_bytes(ctx->split_wgs));
+    // The tickets must read zero when the first launch on this stream starts:
+    // zero them ON that stream (a null-stream memset is not ordered against a
+    // non-blocking stream, and fresh memory holds whatever was there before).
+    hipError_t e = hipMemsetAsync(base, 0, mfma_split_counter_bytes(ctx->split_wgs), stream);
     if (e != hipSuccess) {
       (void)hipFree(base);
       HIP_TRY(e);

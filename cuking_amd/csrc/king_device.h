@@ -95,13 +95,44 @@ __device__ __forceinline__ bool decode_tile(const TiledArgs &a, uint64_t t,
   return true;
 }
 
+// What the record-emitting epilogues need of the launch arguments (small, so
+// that an out-of-line epilogue can take it by value and the kernel's argument
+// struct never has its address taken).
+struct EmitCtx {
+  float kin_threshold;
+  uint32_t max_results;
+  cuking_result *results;
+  uint32_t *result_index;
+  uint32_t *result_overflow;
+  const uint64_t *bits;
+  uint32_t words_per_sample;
+  uint32_t diag, num_rows;
+  uint32_t i_begin, j_begin;
+};
+
+__device__ __forceinline__ EmitCtx make_emit_ctx(const TiledArgs &a) {
+  EmitCtx c;
+  c.kin_threshold = a.kin_threshold;
+  c.max_results = a.max_results;
+  c.results = a.results;
+  c.result_index = a.result_index;
+  c.result_overflow = a.result_overflow;
+  c.bits = a.bits;
+  c.words_per_sample = a.words_per_sample;
+  c.diag = a.geo.diag;
+  c.num_rows = a.geo.num_rows;
+  c.i_begin = a.i_begin;
+  c.j_begin = a.j_begin;
+  return c;
+}
+
 // Lean epilogue of one pair held by every lane (cuking.cu:284-313): the main
 // loop kept the four sums kinship needs.  IBS0 and IBS1 follow from them
 // (ibs1 = exactly one het = hi + hj - 2 bh); IBS2 needs the hom/hom count,
 // which the whole wavefront sums for each of the (few) pairs that pass the
 // threshold.  Must be called by all 64 lanes.
 __device__ __forceinline__ void lean_epilogue_pair(
-    const TiledArgs &a, bool valid, uint32_t li, uint32_t lj, uint32_t het_i,
+    const EmitCtx &a, bool valid, uint32_t li, uint32_t lj, uint32_t het_i,
     uint32_t het_j, uint32_t both_het, uint32_t opp, uint32_t lane) {
   const float kin = king_kinship(het_i, het_j, both_het, opp);
   const bool emit = valid && kin > a.kin_threshold;
@@ -112,7 +143,7 @@ __device__ __forceinline__ void lean_epilogue_pair(
     pending &= pending - 1;
     const uint32_t p_li = __builtin_amdgcn_readlane(li, src);
     const uint32_t p_lj = __builtin_amdgcn_readlane(lj, src);
-    const uint32_t off_j = a.geo.diag ? p_lj : a.geo.num_rows + p_lj;
+    const uint32_t off_j = a.diag ? p_lj : a.num_rows + p_lj;
     const uint32_t sum =
         wave_hom_hom_count(a.bits, a.words_per_sample, p_li, off_j, lane);
     if ((int)lane == src) hom_hom = sum;
@@ -123,6 +154,22 @@ __device__ __forceinline__ void lean_epilogue_pair(
                 het_i + het_j - 2 * both_het, ibs2, a.max_results, a.results,
                 a.result_index, a.result_overflow);
   }
+}
+
+// Cheap, conservative stand-in for `king_kinship(...) > threshold` on the exact
+// float sums (integers < 2^24): false only when the pair certainly fails.  The
+// approximate quotient num * rcp(den) is within 3e-7 relative of the correctly
+// rounded one, the margin is 1e-5 (1 + |q|); den == 0 gives -inf or NaN, which
+// also fail the exact test (both_het <= min(het_i, het_j) = 0 makes num <= 0).
+// Lets the epilogue skip the IEEE divide for the ~all pairs under the
+// threshold; candidates still take the exact path.
+__device__ __forceinline__ bool kinship_may_pass(float het_i, float het_j,
+                                                 float both_het, float opp,
+                                                 float threshold) {
+  const float num = 2.f * both_het - 4.f * opp - het_i - het_j;
+  const float den = 4.f * fminf(het_i, het_j);
+  const float q = num * __builtin_amdgcn_rcpf(den);
+  return q >= (threshold - 0.5f) - 1e-5f * (1.f + fabsf(q));
 }
 
 // Full epilogue of one pair: all six reference sums from the five kept ones.

@@ -375,6 +375,7 @@ __global__ __launch_bounds__(TIT *TJT, MINW) void king_tiled_kernel(
   }
 
   // --- epilogue: kinship, threshold, append (cuking.cu:284-313) ---
+  const EmitCtx emit_ctx = make_emit_ctx(a);
 #pragma unroll
   for (int x = 0; x < RI; ++x) {
     const uint32_t li = tr * TILE + x * TIT + ti;  // row inside the block
@@ -388,8 +389,8 @@ __global__ __launch_bounds__(TIT *TJT, MINW) void king_tiled_kernel(
         full_epilogue_pair(a, valid, li, lj, c_hi[x][y], c_hj[x][y], c_bh[x][y],
                            c_opp[x][y], c_hh[x][y]);
       else
-        lean_epilogue_pair(a, valid, li, lj, c_hi[x][y], c_hj[x][y], c_bh[x][y],
-                           c_opp[x][y], lane);
+        lean_epilogue_pair(emit_ctx, valid, li, lj, c_hi[x][y], c_hj[x][y],
+                           c_bh[x][y], c_opp[x][y], lane);
     }
   }
 }

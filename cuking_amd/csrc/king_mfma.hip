@@ -39,6 +39,9 @@
 #ifndef CUKING_MFMA_STAGES
 #define CUKING_MFMA_STAGES 6
 #endif
+#ifndef CUKING_MFMA_PREFILTER
+#define CUKING_MFMA_PREFILTER 1  // 0: exact kinship for every pair (A/B experiments)
+#endif
 
 namespace cuking {
 
@@ -94,6 +97,16 @@ __device__ __forceinline__ v16f mma(const v8i a, const v8i b, const v16f c) {
       a, b, c, 4 /* A is fp4 */, 4 /* B is fp4 */, 0, scale, 0, scale);
 }
 
+// The exact lean epilogue of one register's pairs, out of line: it is reached
+// for the few pairs that may pass the threshold, and inlined 64 times (with
+// its recount loop and record append) it made the epilogue ~90 KB of code,
+// more than the instruction cache.
+__device__ __attribute__((noinline)) void lean_epilogue_call(
+    const EmitCtx c, bool valid, uint32_t li, uint32_t lj, uint32_t het_i,
+    uint32_t het_j, uint32_t both_het, uint32_t opp, uint32_t lane) {
+  lean_epilogue_pair(c, valid, li, lj, het_i, het_j, both_het, opp, lane);
+}
+
 // `n` MFMAs, each followed by `v` VALU instructions (scheduling request).
 #define CUKING_PACE(n, v)                                                      \
   _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {                         \
@@ -101,8 +114,9 @@ __device__ __forceinline__ v16f mma(const v8i a, const v8i b, const v16f c) {
     if ((v) > 0) __builtin_amdgcn_sched_group_barrier(0x002, (v), 0);          \
   }
 
+// Tickets: one per workgroup and pass (the full form makes two).
 __host__ __device__ inline size_t split_counter_bytes(uint32_t wgs) {
-  return ((size_t)wgs * sizeof(uint32_t) + 255) / 256 * 256;
+  return ((size_t)wgs * 2 * sizeof(uint32_t) + 255) / 256 * 256;
 }
 
 // First work unit of split workgroup w: floor(w * units / wgs).
@@ -125,11 +139,13 @@ __device__ __forceinline__ uint32_t split_owner(uint64_t u, uint64_t units,
 // each partial result (exact integers) is parked in a scratch slab, and the
 // workgroup that delivers a tile's last part adds the others to its own and
 // runs the epilogue.
-// ABLATE (tuning builds, wrong results): 1 = no LDS-DMA, 2 = no barrier either.
+// ABLATE (tuning builds, wrong results): 1 = no LDS-DMA, 2 = no barrier either,
+// 3 = epilogue reduced to one store per lane (prices the kinship/threshold pass).
 template <bool FULL, bool SPLIT, int ABLATE = 0>
 __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   constexpr int NSTAGE = kStages;
   constexpr int NQ = FULL ? 5 : 4;
+  constexpr int BI = FULL ? 1 : 2;  // 32-row blocks per pass over k
   extern __shared__ uint4 lds[];  // [NSTAGE][side][k-group][plane][128]
 
   const uint32_t lane = threadIdx.x & 63;
@@ -174,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   // in flight the same in every iteration, so one counted wait serves the
   // whole loop; the repeats of the last step land in a buffer nobody reads.
   auto issue_piece = [&](uint32_t step, uint32_t buf, int r) {
-    if (ABLATE) return;
+    if (ABLATE == 1 || ABLATE == 2) return;
     if (step >= num_steps) step = num_steps - 1;
     step += k_first;
     const uint32_t piece = wave * kPiecesPerWave + r;  // 0..15
@@ -210,9 +226,14 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     __syncthreads();
   };
 
-  v16f acc[2][2][NQ];
+  // The full form's five sums for 2 x 2 blocks would need 320 accumulator
+  // registers: it makes two passes over k, one per 32-row block (BI = 1), which
+  // fits without spills; the lean form does its 2 x 2 blocks in one pass.
+  for (uint32_t half = 0; half < (FULL ? 2u : 1u); ++half) {
+  const uint32_t half_rows = half * 32;
+  v16f acc[BI][2][NQ];
 #pragma unroll
-  for (int bi = 0; bi < 2; ++bi)
+  for (int bi = 0; bi < BI; ++bi)
 #pragma unroll
     for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
@@ -221,24 +242,27 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
         for (int r = 0; r < 16; ++r) acc[bi][bj][q][r] = 0.f;
 
   // Raw words of the k-step: [block][plane] for the row and the column side.
-  uint4 A[2][2], B[2][2];
+  uint4 A[BI][2], B[2][2];
 #define CUKING_LOAD_RAW(BUF)                                                   \
   {                                                                            \
     const uint4 *l_rows_ = lds + (BUF) * kStageU4 + row_off;                   \
     const uint4 *l_cols_ = lds + (BUF) * kStageU4 + col_off;                   \
-    _Pragma("unroll") for (int b = 0; b < 2; ++b)                              \
     _Pragma("unroll") for (int p = 0; p < 2; ++p) {                            \
-      A[b][p] = l_rows_[p * kTile + b * 32];                                   \
-      B[b][p] = l_cols_[p * kTile + b * 32];                                   \
+      _Pragma("unroll") for (int b = 0; b < BI; ++b)                           \
+        A[b][p] = l_rows_[p * kTile + b * 32 + half_rows];                     \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b)                            \
+        B[b][p] = l_cols_[p * kTile + b * 32];                                 \
     }                                                                          \
   }
 // Fragment set X = planes A, R, H, D of (SA, SB) at the nibble position MASK.
 #define CUKING_EXPAND(X, SA, SB, MASK)                                         \
-  _Pragma("unroll") for (int b = 0; b < 2; ++b) {                              \
+  _Pragma("unroll") for (int b = 0; b < BI; ++b) {                             \
     X##a[b][0] = frag<kA>(SA[b][0], SA[b][1], MASK);                           \
     X##a[b][1] = frag<kR>(SA[b][0], SA[b][1], MASK);                           \
     X##a[b][2] = frag<kH>(SA[b][0], SA[b][1], MASK);                           \
     X##a[b][3] = frag<kD>(SA[b][0], SA[b][1], MASK);                           \
+  }                                                                            \
+  _Pragma("unroll") for (int b = 0; b < 2; ++b) {                              \
     X##b[b][0] = frag<kA>(SB[b][0], SB[b][1], MASK);                           \
     X##b[b][1] = frag<kR>(SB[b][0], SB[b][1], MASK);                           \
     X##b[b][2] = frag<kH>(SB[b][0], SB[b][1], MASK);                           \
@@ -247,7 +271,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
 // One plane product (fragment index PA of the rows x PB of the columns) for
 // the four block pairs.
 #define CUKING_MMA1(F, X, PA, PB, Q)                                           \
-  _Pragma("unroll") for (int bi = 0; bi < 2; ++bi)                             \
+  _Pragma("unroll") for (int bi = 0; bi < BI; ++bi)                            \
   _Pragma("unroll") for (int bj = 0; bj < 2; ++bj)                             \
     acc[bi][bj][Q] = mma<F>(X##a[bi][PA], X##b[bj][PB], acc[bi][bj][Q]);
 // opp (first half), bh, hi, hj: 16 MFMAs; then the second half of opp.
@@ -260,30 +284,29 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   for (int st = 0; st < NSTAGE - 1; ++st) issue_stage(st, st);
   stage_sync();
 
-  if (FULL) {
-    // Five accumulator sets leave no room for a second fragment set: plain
-    // loop, the compiler's order.
+  if constexpr (FULL) {
+    // One row block, five sums, six products: plain loop, the compiler's order.
     uint32_t buf = 0;
     asm volatile("" : "+v"(row_off), "+v"(col_off), "+v"(lane16));
     for (uint32_t step = 0; step < num_steps; ++step) {
       if (step != 0) stage_sync();
       issue_stage(step + NSTAGE - 1, buf == 0 ? NSTAGE - 1 : buf - 1);
       CUKING_LOAD_RAW(buf)
-      uint4 As[2][2], Bs[2][2];
+      uint4 As[BI][2], Bs[2][2];
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int p = 0; p < 2; ++p) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          As[b][p] = shr3(A[b][p]);
-          Bs[b][p] = shr3(B[b][p]);
-        }
+        for (int b = 0; b < BI; ++b) As[b][p] = shr3(A[b][p]);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) Bs[b][p] = shr3(B[b][p]);
+      }
 #define CUKING_FULL_STEP(F, SA, SB, MASK)                                      \
       {                                                                        \
-        v8i Xa[2][4], Xb[2][4];                                                \
+        v8i Xa[BI][4], Xb[2][4];                                               \
         CUKING_EXPAND(X, SA, SB, MASK)                                         \
         CUKING_MMA16(F, X)                                                     \
         CUKING_MMA4(F, X)                                                      \
-        _Pragma("unroll") for (int bi = 0; bi < 2; ++bi)                       \
+        _Pragma("unroll") for (int bi = 0; bi < BI; ++bi)                      \
         _Pragma("unroll") for (int bj = 0; bj < 2; ++bj)                       \
           acc[bi][bj][NQ - 1] =                                                \
               mma<F>(frag<kY>(SA[bi][0], SA[bi][1], MASK),                     \
@@ -389,25 +412,29 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
 #undef CUKING_MMA4
 
   if (SPLIT && num_steps != tile_steps) {
-    // Partial tile: park this part in its own slab (plain 16-byte stores,
+    // Partial tile: park this part in its own slab (16-byte stores,
     // lane-linear [wave][block pair][sum][4 registers][lane]), then take a
     // ticket of the tile.  Slab of a part: 2 * workgroup + (0 for the piece in
-    // the workgroup's first tile, 1 for the piece in its second).
-    constexpr size_t kSlabU4 = 4 * 4 * NQ * 4 * 64;  // uint4 per slab
+    // the workgroup's first tile, 1 for the piece in its second); the full
+    // form's two passes use the two halves of the slab and a ticket each.
+    constexpr size_t kSlabU4 = 4 * 4 * 4 * 4 * 64;        // uint4 per slab (lean)
+    constexpr size_t kPassU4 = 4 * BI * 2 * NQ * 4 * 64;  // ... per pass
+    static_assert(kPassU4 * (FULL ? 2 : 1) <= kSlabU4 * 5 / 4, "slab size");
     const uint64_t first_unit = (uint64_t)seg_tile * tile_steps;
     const uint64_t my_first = split_bound(blockIdx.x, units, a.split_wgs);
     const uint32_t my_slab = 2 * blockIdx.x + (my_first / tile_steps == seg_tile ? 0 : 1);
-    float4 *slabs = reinterpret_cast<float4 *>(a.split_scratch);
+    float4 *slabs = reinterpret_cast<float4 *>(a.split_scratch) + half * kPassU4;
+    constexpr size_t kSlabStride = kSlabU4 * 5 / 4;  // sized for the full form
     {
       // Write-through (sc1) 16-byte stores: the data is in memory when the
       // wait below returns, so no release fence (which would write back the
       // whole L2: tens of microseconds with 256 KiB freshly dirtied).
       typedef uint32_t v4u __attribute__((ext_vector_type(4)));
       const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          slabs + my_slab * kSlabU4, 0, (int)(kSlabU4 * 16), 0x00020000);
-      const int base = (int)((wave * (4 * NQ * 4 * 64) + lane) * 16);
+          slabs + my_slab * kSlabStride, 0, (int)(kPassU4 * 16), 0x00020000);
+      const int base = (int)((wave * (BI * 2 * NQ * 4 * 64) + lane) * 16);
 #pragma unroll
-      for (int bi = 0; bi < 2; ++bi)
+      for (int bi = 0; bi < BI; ++bi)
 #pragma unroll
         for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
@@ -432,15 +459,16 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     const uint32_t w_first = split_owner(first_unit, units, a.split_wgs);
     const uint32_t w_last = split_owner(first_unit + tile_steps - 1, units, a.split_wgs);
     if (threadIdx.x == 0) {
-      // One counter per workgroup: a workgroup owns the first unit of at most
-      // one tile that continues into the next workgroup.
+      // One counter per workgroup (and pass): a workgroup owns the first unit
+      // of at most one tile that continues into the next workgroup.
+      uint32_t *counter = a.split_counters + half * a.split_wgs + w_first;
       const uint32_t ticket = __hip_atomic_fetch_add(
-          a.split_counters + w_first, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const bool last = ticket == w_last - w_first;
       if (last) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        a.split_counters[w_first] = 0;  // ready for the next launch
+        *counter = 0;  // ready for the next launch
       }
       *flag = last ? 1u : 0u;
     }
@@ -453,9 +481,10 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       if (w == blockIdx.x) continue;
       const uint32_t slab =
           2 * w + (split_bound(w, units, a.split_wgs) / tile_steps == seg_tile ? 0 : 1);
-      const float4 *src = slabs + slab * kSlabU4 + (size_t)wave * (4 * NQ * 4 * 64) + lane;
+      const float4 *src =
+          slabs + slab * kSlabStride + (size_t)wave * (BI * 2 * NQ * 4 * 64) + lane;
 #pragma unroll
-      for (int bi = 0; bi < 2; ++bi)
+      for (int bi = 0; bi < BI; ++bi)
 #pragma unroll
         for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
@@ -471,33 +500,57 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     }
   }
 
+  if (ABLATE == 3) {
+    float sum = 0.f;
+#pragma unroll
+    for (int bi = 0; bi < BI; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sum += acc[bi][bj][q][r];
+    if (sum == -1.f) a.results[0].kin = sum;  // never true, keeps the sums alive
+    continue;
+  }
   // --- epilogue: kinship, threshold, append (cuking.cu:284-313).  C layout of
   // the 32 x 32 MFMA: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+  const EmitCtx emit_ctx = make_emit_ctx(a);
 #pragma unroll
-  for (int bi = 0; bi < 2; ++bi) {
+  for (int bi = 0; bi < BI; ++bi) {
 #pragma unroll
     for (int bj = 0; bj < 2; ++bj) {
       const uint32_t lj = tc * kTile + wc + bj * 32 + lr;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const uint32_t li =
-            tr * kTile + wr + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            tr * kTile + wr + half_rows + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
         // cuking.cu:199 plus the tile padding
         const bool valid = li < a.geo.num_rows && lj < a.geo.num_cols &&
                            a.i_begin + li < a.j_begin + lj;
-        const uint32_t opp = (uint32_t)acc[bi][bj][0][r];
-        const uint32_t bh = (uint32_t)acc[bi][bj][1][r];
-        const uint32_t hi = (uint32_t)acc[bi][bj][2][r];
-        const uint32_t hj = (uint32_t)acc[bi][bj][3][r];
-        if (FULL)
-          full_epilogue_pair(a, valid, li, lj, hi, hj, bh, opp,
-                             (uint32_t)acc[bi][bj][NQ - 1][r]);
-        else
-          lean_epilogue_pair(a, valid, li, lj, hi, hj, bh, opp, lane);
+        if (FULL) {
+          full_epilogue_pair(a, valid, li, lj, (uint32_t)acc[bi][bj][2][r],
+                             (uint32_t)acc[bi][bj][3][r], (uint32_t)acc[bi][bj][1][r],
+                             (uint32_t)acc[bi][bj][0][r], (uint32_t)acc[bi][bj][NQ - 1][r]);
+        } else {
+          // Nearly every pair fails the threshold: decide that on the float
+          // sums without the IEEE divide, and only when some lane of the
+          // wavefront may pass run the exact epilogue (wave-uniform branch).
+          const bool maybe =
+              !CUKING_MFMA_PREFILTER ||
+              (valid && kinship_may_pass(acc[bi][bj][2][r], acc[bi][bj][3][r],
+                                        acc[bi][bj][1][r], acc[bi][bj][0][r],
+                                        a.kin_threshold));
+          if (__ballot(maybe) != 0)
+            lean_epilogue_call(emit_ctx, valid, li, lj, (uint32_t)acc[bi][bj][2][r],
+                               (uint32_t)acc[bi][bj][3][r], (uint32_t)acc[bi][bj][1][r],
+                               (uint32_t)acc[bi][bj][0][r], lane);
+        }
       }
     }
   }
-  if (SPLIT) __syncthreads();  // LDS is reused by the next piece
+  if (SPLIT || FULL) __syncthreads();  // LDS is reused by the next pass / piece
+  }  // passes (full form: two)
   }  // pieces of this workgroup
 }
 
@@ -549,6 +602,7 @@ hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
   if (const char *e = getenv("CUKING_MFMA_ABLATE")) {
     if (e[0] == '1') return launch_shape<false, false, 1>(args, num_tiles, lds_bytes, stream);
     if (e[0] == '2') return launch_shape<false, false, 2>(args, num_tiles, lds_bytes, stream);
+    if (e[0] == '3') return launch_shape<false, false, 3>(args, num_tiles, lds_bytes, stream);
   }
 #endif
   // Short launches (a few tiles per CU or fewer: small blocks, the rectangles

@@ -3,7 +3,7 @@
 splitting (king_mfma.hip): blocks large enough that pieces of k-steps, scratch
 slabs and tickets are really exercised -- whole blocks, tile sub-ranges and the
 staged rectangles on several streams at once (one slab per stream).
-usage: fuzz_split.py [seed] [cases]"""
+usage: fuzz_split.py [seed] [cases] [first_case]   (first_case: replay one failure)"""
 import sys
 import time
 from pathlib import Path
@@ -18,6 +18,7 @@ from oracle import pyoracle
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+first_case = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 rng = np.random.default_rng(seed)
 ctx = cuking_amd.KingContext(0)
 ctx.set_kernel("tiled"); ctx.set_option("variant", 5)
@@ -27,6 +28,11 @@ for case in range(cases):
     thr = float(rng.choice([0.03, 0.0884, 0.3]))
     mode = int(rng.choice([-1, -1, 0, 1]))
     wgs = int(rng.choice([3, 16, 64, 256, 256]))
+    w = int(rng.integers(2, 6))
+    world = int(rng.integers(1, 5)); chunks = int(rng.integers(1, 6))
+    streams = [int(rng.integers(1, 4)) for _ in range(world)]
+    if case < first_case:
+        continue
     ctx.set_option("split_wgs", wgs); ctx.set_option("counts_mode", mode)
     cohort = plan_cohort(n, seed * 1000 + case)
     kind, pa, pb = cohort_to_device(cohort, 0)
@@ -42,15 +48,13 @@ for case in range(cases):
         got = ctx.run(sm, wps, d_bits, thr)
         assert got.tobytes() == exp.tobytes(), ("run", rep, tag)
     tiles = ctx.num_tiles(sm)
-    w = int(rng.integers(2, 6))
     parts = [ctx.run(sm, wps, d_bits, thr, tile_range=r) for r in tile_partition(tiles, w)]
     merged = cuking_amd.sort_results(np.ascontiguousarray(np.concatenate(parts)))
     assert merged.tobytes() == exp.tobytes(), ("tiles", w, tag)
-    world = int(rng.integers(1, 5)); chunks = int(rng.integers(1, 6))
     parts = []
     for rank in range(world):
         ops = GpuStagedOps(ctx, sm, wps, d_bits, thr, max(len(exp), 1) + 8,
-                           num_streams=int(rng.integers(1, 4)))
+                           num_streams=streams[rank])
         ops.begin()
         for (c0, c1), rect in staged_schedule(n, ctx.tile_samples(), world, rank, chunks):
             if rect is None: continue
@@ -60,7 +64,12 @@ for case in range(cases):
         parts.append(res[:cnt].cpu().numpy().view(np.uint32).reshape(-1).view(
             cuking_amd.KING_RESULT_DTYPE).copy())
     merged = cuking_amd.sort_results(np.ascontiguousarray(np.concatenate(parts)))
-    assert merged.tobytes() == exp.tobytes(), ("staged", world, chunks, tag)
+    if merged.tobytes() != exp.tobytes():
+        have = {(int(r["sample_i"]), int(r["sample_j"])) for r in merged}
+        want = {(int(r["sample_i"]), int(r["sample_j"])) for r in exp}
+        print("staged mismatch", world, chunks, streams, tag, "records", len(merged), len(exp),
+              "missing", sorted(want - have)[:8], "extra", sorted(have - want)[:8], flush=True)
+        raise SystemExit(1)
     if case % 5 == 0:
         print(f"case {case} ok {tag} records {len(exp)} ({time.time() - t0:.0f}s)", flush=True)
 print(f"fuzz_split seed {seed}: {cases} cases OK in {time.time() - t0:.0f}s", flush=True)
