@@ -388,6 +388,23 @@ def test_matrix_core_float_limit(ctx, oracle, sites, expect_fallback):
     select(ctx, "tiled", 0)
 
 
+def test_options_round_trip(ctx):
+    """cuking_ctx_get_option reads back what set_option stored; the default
+    kernel variant is the matrix-core one."""
+    fresh = cuking_amd.KingContext(0)
+    try:
+        assert fresh.get_option("variant") == 5 and fresh.variant_name() == "t128_mfma_fp4"
+        assert fresh.get_option("split_wgs") > 0 and fresh.get_option("counts_mode") == -1
+        for key, value in (("variant", 2), ("band_rows", 9), ("counts_mode", 1), ("split_wgs", 0)):
+            fresh.set_option(key, value)
+            assert fresh.get_option(key) == value
+        assert fresh.tile_samples() == 128
+        with pytest.raises(cuking_amd.CukingError):
+            fresh.get_option("no_such_option")
+    finally:
+        fresh.close()
+
+
 def test_appending_calls_share_one_buffer(ctx, oracle):
     """result_index is not reset by the call (cuking.cu:721-722 leaves that to
     the caller), so shards can append into one buffer."""
