@@ -23,12 +23,14 @@
 // inside the k dimension is irrelevant as long as both operands agree.
 //
 // Workgroup = 128 x 128 pairs, 4 wavefronts (one per SIMD, up to 512
-// registers each), each 64 x 64 pairs = 2 x 2 MFMA blocks x 4 (5) float32
-// accumulator sets.  One k-step = 256 sites = for every lane one uint4 (four
-// 32-site words) per plane and block, read from LDS with ds_read_b128 and
-// expanded four times (f = 0..3): 80 (96) MFMAs per k-step and wavefront.
-// The planes come from the quad layout (king_common.h) by LDS-DMA, 16 KiB per
-// k-step, three stages deep.
+// registers each), each 64 x 64 pairs = 2 x 2 MFMA blocks x 4 float32
+// accumulator sets (lean form; the full form keeps 5 sets for 1 x 2 blocks and
+// makes two passes over k).  One k-step = 256 sites = for every lane one uint4
+// (four 32-site words) per plane and block, read from LDS with ds_read_b128
+// and expanded four times (f = 0..3): 80 MFMAs per k-step and wavefront.  The
+// planes come from the quad layout (king_common.h) by LDS-DMA, 16 KiB per
+// k-step, kStages stages deep.  DESIGN.md 4.1 has the measurements behind the
+// choices; profiles/r01_mfma_microbench.txt the raw numbers.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
