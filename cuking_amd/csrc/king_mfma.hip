@@ -610,7 +610,8 @@ hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
   // Short launches (a few tiles per CU or fewer: small blocks, the rectangles
   // of the staged multi-GPU schedule) run whole rounds of one tile per
   // workgroup and then the remainder cut into equal pieces over all CUs
-  // (measured: 36 tiles 0.57 -> 0.25 ms, 820 tiles 2.40 -> 2.20 ms); under two
+  // (measured: 36 tiles 0.57 -> 0.25 ms, 820 tiles 2.40 -> 2.20 ms, 1128 tiles
+  // 2.92 -> 2.78 ms); under two
   // tiles per CU the whole launch goes out as pieces.  With
   // many rounds the dispatcher's own back-filling does as well and the second
   // launch's boundary costs more than it saves (3160 tiles: +1 %), so long
@@ -625,8 +626,9 @@ hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
       rest = (uint32_t)num_tiles;
     } else {
       rest = (uint32_t)(num_tiles % wgs);
-      // not worth it when the remainder nearly fills the chip
-      if (rest * 8 > wgs * 7) rest = 0;
+      // not worth it when the remainder fills most of the chip anyway
+      // (2016 tiles, remainder 224 of 256: 4.50 -> 4.58 ms)
+      if (rest * 2 > wgs) rest = 0;
     }
     if ((uint64_t)rest * tile_steps < 8ull * wgs) rest = 0;  // too little work to cut up
     whole = num_tiles - rest;
