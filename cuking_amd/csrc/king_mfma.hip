@@ -172,9 +172,25 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   const uint64_t units = (uint64_t)a.split_tiles * tile_steps;
   uint64_t unit_lo = SPLIT ? split_bound(blockIdx.x, units, a.split_wgs)
                            : (uint64_t)blockIdx.x * tile_steps;
-  const uint64_t unit_hi = SPLIT ? split_bound(blockIdx.x + 1, units, a.split_wgs)
-                                 : unit_lo + tile_steps;
-  while (unit_lo < unit_hi) {
+  uint64_t unit_hi = SPLIT ? split_bound(blockIdx.x + 1, units, a.split_wgs)
+                           : unit_lo + tile_steps;
+#ifdef CUKING_TUNING
+  // experiment (split_wgs with the top bit set): persistent workgroups, whole
+  // tiles blockIdx.x, blockIdx.x + grid, ... of the launch's split_tiles.
+  const bool strided = SPLIT && (a.split_wgs & 0x80000000u) != 0;
+  uint64_t next_tile = blockIdx.x;
+  if (strided) unit_lo = unit_hi = 0;
+#else
+  constexpr bool strided = false;
+  uint64_t next_tile = 0;
+#endif
+  while (true) {
+  if (unit_lo >= unit_hi) {
+    if (!strided || next_tile >= a.split_tiles) break;
+    unit_lo = next_tile * tile_steps;
+    unit_hi = unit_lo + tile_steps;
+    next_tile += gridDim.x;
+  }
   const uint32_t seg_tile = (uint32_t)(unit_lo / tile_steps);  // within the launch
   const uint32_t k_first = (uint32_t)(unit_lo - (uint64_t)seg_tile * tile_steps);
   const uint32_t num_steps = (unit_hi - unit_lo < (uint64_t)(tile_steps - k_first))
@@ -641,6 +657,15 @@ hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
       num_tiles < 0xFFFFFFFFull && num_tiles * tile_steps >= 8ull * wgs) {
     rest = (uint32_t)num_tiles;
     whole = 0;
+  }
+  // experiment: persistent workgroups striding over whole tiles
+  if (getenv("CUKING_MFMA_PERSIST") && wgs != 0 && args.split_scratch != nullptr &&
+      num_tiles < 0x7FFFFFFFull && num_tiles > wgs) {
+    TiledArgs pa = args;
+    pa.split_tiles = (uint32_t)num_tiles;
+    pa.split_wgs = wgs | 0x80000000u;
+    return full ? launch_shape<true, true>(pa, wgs, lds_bytes, stream)
+                : launch_shape<false, true>(pa, wgs, lds_bytes, stream);
   }
 #endif
   if (getenv("CUKING_AMD_DEBUG"))
