@@ -437,7 +437,11 @@ Status Run(const Flags &flags) {
             << std::setprecision(1) << rate << ", \"algorithmic_GBps\": "
             << rate * cuking_bytes_per_pair(words_per_sample) / 1e9
             << ", \"hbm_roofline_fraction\": " << std::setprecision(3)
-            << rate * cuking_bytes_per_pair(words_per_sample) / 8e12 << "}" << std::endl;
+            << rate * cuking_bytes_per_pair(words_per_sample) / 8e12
+            // five plane products per pair and site on the matrix cores, 2 FLOP
+            // each (the default kernel; king_mfma.hip)
+            << ", \"algorithmic_PFLOPs\": " << rate * 10.0 * metadata.num_sites / 1e15 << "}"
+            << std::endl;
   return Status::Ok();
 }
 
