@@ -226,9 +226,14 @@ def main():
         index_flag.zero_()
         ctx.compute_king(sm, wps, bit_sets, thr, args.max_results, results,
                          index_flag[0:1], index_flag[1:2], tile_range=(begin, end))
+        if device_gather:
+            return results, index_flag     # counts stay on the device until the gather
         count, ovf = index_flag.tolist()   # waits for the kernel
         return results, count, ovf
 
+    # nccl gathers straight from the kernel's own counters; gloo (one-GPU
+    # rehearsals) needs host tensors and takes the staging path
+    device_gather = use_dist and dist.get_backend() == "nccl"
     gathered = [None]
     staged = use_dist and args.dist_mode == "staged" and args.kernel == "tiled"
     tile = ctx.tile_samples()

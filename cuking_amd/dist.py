@@ -93,19 +93,73 @@ def gather_results(local, count: int, overflow: int, dst: int = 0,
     return sort_results(recs)
 
 
+def gather_results_device(local, index_flag, dst: int = 0, group=None,
+                          fast_rows: int = 8192) -> Optional[np.ndarray]:
+    """Exchange step 2 without a host round trip before the collective.
+    ``index_flag`` is the kernel's own device tensor [count, overflow] (int32).
+    Fast path: ONE all-gather of a fixed block per rank -- a header row with
+    the two counters, then the first ``fast_rows`` records -- and one copy to
+    the host; every rank sees every count, so all of them agree on whether the
+    block was enough.  Otherwise (a rank has more records) the counts are
+    already known and a padded gather follows, as in gather_results()."""
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    fast_rows = min(fast_rows, local.shape[0])
+    block = torch.empty((fast_rows + 1, 6), dtype=torch.int32, device=local.device)
+    block[0, :2] = index_flag
+    block[1:] = local[:fast_rows]
+    parts = [torch.empty_like(block) for _ in range(world)]
+    dist.all_gather(parts, block, group=group)     # (gloo has no all_gather_into_tensor)
+    blocks = torch.stack(parts)
+    if rank == dst:
+        host = blocks.cpu().numpy()              # the one synchronisation point
+        heads = host[:, 0, :2]
+    else:
+        host = None
+        heads = blocks[:, 0, :2].cpu().numpy()
+    counts = [int(c) for c in heads[:, 0]]
+    if heads[:, 1].any():
+        raise ResourceExhaustedError(
+            "Could not store all results: try increasing the --max_results "
+            "parameter.")
+    if max(counts) <= fast_rows:
+        if rank != dst:
+            return None
+        flat = np.concatenate([host[r, 1:1 + counts[r]] for r in range(world)], axis=0)
+    else:
+        width = max(counts)
+        if width > local.shape[0]:
+            raise ResourceExhaustedError("record buffer smaller than another rank's count")
+        send = local[:width]
+        recv = ([torch.empty_like(send) for _ in range(world)] if rank == dst else None)
+        dist.gather(send, recv, dst=dst, group=group)
+        if rank != dst:
+            return None
+        flat = torch.cat([recv[r][:counts[r]] for r in range(world)], dim=0).cpu().numpy()
+    recs = np.ascontiguousarray(flat).view(np.uint32).reshape(-1).view(KING_RESULT_DTYPE).copy()
+    return sort_results(recs)
+
+
 def all_pairs_king(compute_tiles: Callable, num_tiles: int, bit_sets,
                    src: int = 0, dst: int = 0, group=None,
                    broadcast: bool = True):
     """One sharded pass.  ``compute_tiles(bit_sets, tile_begin, tile_end)``
     must return (records tensor [cap, 6] int32, count, overflow) for its tile
-    range.  Returns (sorted records on dst else None, (tile_begin, tile_end))."""
+    range -- or (records tensor, index_flag device tensor [count, overflow]),
+    which skips the host round trip before the gather (nccl only).  Returns
+    (sorted records on dst else None, (tile_begin, tile_end))."""
     import torch.distributed as dist
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
     if broadcast:
         broadcast_bitset(bit_sets, src=src, group=group)
     begin, end = tile_partition(num_tiles, world)[rank]
-    local, count, overflow = compute_tiles(bit_sets, begin, end)
+    out = compute_tiles(bit_sets, begin, end)
+    if len(out) == 2:
+        return gather_results_device(out[0], out[1], dst=dst, group=group), (begin, end)
+    local, count, overflow = out
     return gather_results(local, count, overflow, dst=dst, group=group), (begin, end)
 
 

@@ -215,3 +215,41 @@ def test_staged_schedule_covers_every_pair_once(n, tile, world, chunks):
     assert abs(sum(shares) - 1.0) < 1e-12
     if t >= 16 * world:
         assert max(shares) <= 1.1 / world
+
+
+def _device_gather_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cuking_amd.api import ResourceExhaustedError
+    from cuking_amd.dist import gather_results, gather_results_device
+    ok = True
+    for fast_rows in (4, 64):                      # fallback gather / one-collective path
+        count = 10 + 7 * rank
+        rng = np.random.default_rng(100 + rank)
+        local = torch.from_numpy(rng.integers(0, 1000, size=(100, 6)).astype(np.int32))
+        flag = torch.tensor([count, 0], dtype=torch.int32)
+        a = gather_results_device(local, flag, fast_rows=fast_rows)
+        b = gather_results(local, count, 0)
+        if rank == 0:
+            ok &= a.tobytes() == b.tobytes() and len(a) == sum(10 + 7 * r for r in range(world))
+        else:
+            ok &= a is None and b is None
+    # an overflow flag on any rank fails every rank
+    flag = torch.tensor([3, 1 if rank == world - 1 else 0], dtype=torch.int32)
+    try:
+        gather_results_device(local, flag)
+        ok = False
+    except ResourceExhaustedError:
+        pass
+    Path(f"{out_path}.{rank}").write_text("ok" if ok else "bad")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_device_side_gather_matches_host_gather(tmp_path, world):
+    """gather_results_device (counters taken from the kernel's own device
+    tensor, one all-gather on the fast path) == gather_results."""
+    out = tmp_path / "res"
+    mp.spawn(_device_gather_worker, args=(world, _free_port(), str(out)), nprocs=world, join=True)
+    assert all(Path(f"{out}.{r}").read_text() == "ok" for r in range(world))
