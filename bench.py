@@ -13,7 +13,7 @@ every (i < j) pair + thresholded append of KingResult records.  For N > 1 a
 step is the sharded pass of cuking_amd/dist.py: every rank holds the bitset
 (as every shard of the reference reads the whole input itself), evaluates its
 range of pair-space tiles, and the records are gathered on rank 0 -- the only
-collective.  --dist-mode staged / simple instead start from a bitset that only
+collective; the gather of one pass runs behind the kernel of the next.  --dist-mode staged / simple instead start from a bitset that only
 rank 0 holds and count its RCCL broadcast in the step.
 
 N = 1 workload: BASELINE.json configs[1], 10k samples x 100k sites,
@@ -163,7 +163,7 @@ def main():
     import torch
     import torch.distributed as dist
     import cuking_amd
-    from cuking_amd.dist import (GpuStagedOps, all_pairs_king,
+    from cuking_amd.dist import (GpuStagedOps, PipelinedGather, all_pairs_king,
                                  all_pairs_king_staged, rank_tile_share,
                                  tile_partition)
     from cuking_amd.synth import cohort_to_device, plan_cohort
@@ -219,6 +219,10 @@ def main():
 
     results = torch.zeros((args.max_results, 6), dtype=torch.int32, device=dev)
     index_flag = torch.zeros(2, dtype=torch.int32, device=dev)
+    # second record buffer: with nccl the gather of one pass overlaps the
+    # kernel of the next (cuking_amd.dist.PipelinedGather)
+    results_b = torch.zeros_like(results) if use_dist else None
+    index_flag_b = torch.zeros_like(index_flag) if use_dist else None
     num_tiles = ctx.num_tiles(sm) if args.kernel == "tiled" else 0
     my_tiles = tile_partition(num_tiles, world)[rank] if use_dist else None
 
@@ -241,7 +245,34 @@ def main():
                                num_streams=args.streams)
                   if staged else None)
 
+    pipelined = (use_dist and device_gather and args.dist_mode == "resident" and
+                 args.kernel == "tiled" and
+                 os.environ.get("CUKING_BENCH_NO_PIPELINE") != "1")
+    pipe = PipelinedGather() if pipelined else None
+    pending = [None]
+    parity = [0]
+
+    def pipelined_step():
+        # pass k: kernel into buffer k % 2, its gather starts behind it; then the
+        # gather of pass k - 1 is collected while this pass's kernel runs
+        buf, flag = ((results, index_flag), (results_b, index_flag_b))[parity[0]]
+        parity[0] ^= 1
+        flag.zero_()
+        ctx.compute_king(sm, wps, bits, thr, args.max_results, buf, flag[0:1], flag[1:2],
+                         tile_range=my_tiles)
+        handle = pipe.begin(buf, flag)
+        if pending[0] is not None:
+            gathered[0] = pipe.finish(pending[0])
+        pending[0] = handle
+
+    def drain():
+        if pending[0] is not None:
+            gathered[0] = pipe.finish(pending[0])
+            pending[0] = None
+
     def step():
+        if pipelined:
+            return pipelined_step()
         if not use_dist:
             index_flag.zero_()
             ctx.compute_king(sm, wps, bits, thr, args.max_results, results,
@@ -260,11 +291,15 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if pipelined:
+        drain()
     barrier()
     ctx.timing_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if pipelined:
+        drain()          # the last pass's records are on rank 0 before the clock stops
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:

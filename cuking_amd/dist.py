@@ -142,6 +142,62 @@ def gather_results_device(local, index_flag, dst: int = 0, group=None,
     return sort_results(recs)
 
 
+class PipelinedGather:
+    """gather_results_device() split in two so that the exchange of one pass
+    overlaps the kernel of the next (nccl): ``begin`` assembles the block on
+    the compute stream (i.e. after the pass's kernel) and starts the all-gather
+    asynchronously; ``finish`` -- called while the next pass's kernel runs --
+    copies the gathered blocks to the host on a side stream and returns the
+    sorted records on ``dst``.  Use two record buffers alternately: a buffer
+    may be written again once ``finish`` of its pass has returned."""
+
+    def __init__(self, dst: int = 0, group=None, fast_rows: int = 8192):
+        import torch
+        self.dst, self.group, self.fast_rows = dst, group, fast_rows
+        self.side = torch.cuda.Stream()
+
+    def begin(self, local, index_flag):
+        import torch
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group)
+        rows = min(self.fast_rows, local.shape[0])
+        block = torch.empty((rows + 1, 6), dtype=torch.int32, device=local.device)
+        block[0, :2] = index_flag
+        block[1:] = local[:rows]
+        parts = [torch.empty_like(block) for _ in range(world)]
+        work = dist.all_gather(parts, block, group=self.group, async_op=True)
+        return {"local": local, "rows": rows, "parts": parts, "work": work, "block": block}
+
+    def finish(self, h):
+        import torch
+        import torch.distributed as dist
+        rank = dist.get_rank(self.group)
+        world = dist.get_world_size(self.group)
+        with torch.cuda.stream(self.side):
+            h["work"].wait()                      # side stream waits for the all-gather
+            blocks = torch.stack(h["parts"])
+            host = (blocks if rank == self.dst else blocks[:, 0, :2]).to("cpu", non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        done.synchronize()                        # not the compute stream
+        host = host.numpy()
+        heads = host[:, 0, :2] if rank == self.dst else host
+        counts = [int(c) for c in heads[:, 0]]
+        if heads[:, 1].any():
+            raise ResourceExhaustedError(
+                "Could not store all results: try increasing the --max_results "
+                "parameter.")
+        if max(counts) > h["rows"]:
+            # rare: somebody has more records than the block holds
+            return gather_results(h["local"], counts[rank], 0, dst=self.dst, group=self.group)
+        if rank != self.dst:
+            return None
+        flat = np.concatenate([host[r, 1:1 + counts[r]] for r in range(world)], axis=0)
+        recs = np.ascontiguousarray(flat).view(np.uint32).reshape(-1).view(
+            KING_RESULT_DTYPE).copy()
+        return sort_results(recs)
+
+
 def all_pairs_king(compute_tiles: Callable, num_tiles: int, bit_sets,
                    src: int = 0, dst: int = 0, group=None,
                    broadcast: bool = True):
