@@ -349,6 +349,7 @@ cuking_status run_tiled(cuking_ctx *ctx, const cuking_submatrix &sm,
   a.bits = d_bit_sets;
   a.words_per_sample = words_per_sample;
   a.split_tiles = 0;
+  a.split_whole = 0;
   a.split_wgs = ctx->split_wgs;
   st = split_scratch_for(ctx, stream, &a.split_scratch, &a.split_counters);
   if (st != CUKING_OK) return st;
@@ -919,6 +920,7 @@ cuking_status cuking_compute_king_rect(
   a.bits = d_bit_sets;
   a.words_per_sample = words_per_sample;
   a.split_tiles = 0;
+  a.split_whole = 0;
   a.split_wgs = ctx->split_wgs;
   st = split_scratch_for(ctx, (hipStream_t)stream, &a.split_scratch, &a.split_counters);
   if (st != CUKING_OK) return st;

@@ -123,6 +123,9 @@ struct TiledArgs {
   // results are parked in split_scratch, tickets in split_counters (zero
   // between launches).  split_wgs == 0 or no scratch: never split.
   uint32_t split_tiles, split_wgs;
+  // ... preceded, in the same launch, by split_whole workgroups that take one
+  // whole tile each (tiles tile_begin .. tile_begin + split_whole - 1).
+  uint32_t split_whole;
   uint32_t *split_scratch, *split_counters;
 };
 

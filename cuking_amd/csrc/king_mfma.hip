@@ -169,11 +169,17 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   asm volatile("s_mov_b32 %0, 0x44444444" : "=s"(m4));
 
   // Work units [unit_lo, unit_hi) of this workgroup; unit = (tile, k-step).
-  const uint64_t units = (uint64_t)a.split_tiles * tile_steps;
-  uint64_t unit_lo = SPLIT ? split_bound(blockIdx.x, units, a.split_wgs)
-                           : (uint64_t)blockIdx.x * tile_steps;
-  uint64_t unit_hi = SPLIT ? split_bound(blockIdx.x + 1, units, a.split_wgs)
-                           : unit_lo + tile_steps;
+  // SPLIT launches: the first split_whole workgroups take one whole tile each,
+  // the remaining split_wgs ones cut the units of the last split_tiles tiles
+  // into equal pieces (piece index `piece`).
+  const uint64_t units = (uint64_t)a.split_tiles * tile_steps;      // of the cut-up tiles
+  const uint64_t whole_units = SPLIT ? (uint64_t)a.split_whole * tile_steps : 0;
+  const bool whole_wg = !SPLIT || blockIdx.x < a.split_whole;
+  const uint32_t piece = SPLIT && !whole_wg ? blockIdx.x - a.split_whole : 0;
+  uint64_t unit_lo = whole_wg ? (uint64_t)blockIdx.x * tile_steps
+                              : whole_units + split_bound(piece, units, a.split_wgs);
+  uint64_t unit_hi = whole_wg ? unit_lo + tile_steps
+                              : whole_units + split_bound(piece + 1, units, a.split_wgs);
 #ifdef CUKING_TUNING
   // experiment (split_wgs with the top bit set): persistent workgroups, whole
   // tiles blockIdx.x, blockIdx.x + grid, ... of the launch's split_tiles.
@@ -438,9 +444,12 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     constexpr size_t kSlabU4 = 4 * 4 * 4 * 4 * 64;        // uint4 per slab (lean)
     constexpr size_t kPassU4 = 4 * BI * 2 * NQ * 4 * 64;  // ... per pass
     static_assert(kPassU4 * (FULL ? 2 : 1) <= kSlabU4 * 5 / 4, "slab size");
-    const uint64_t first_unit = (uint64_t)seg_tile * tile_steps;
-    const uint64_t my_first = split_bound(blockIdx.x, units, a.split_wgs);
-    const uint32_t my_slab = 2 * blockIdx.x + (my_first / tile_steps == seg_tile ? 0 : 1);
+    // (positions inside the cut-up part of the launch: tile and units count
+    // from its first tile)
+    const uint32_t cut_tile = seg_tile - a.split_whole;
+    const uint64_t first_unit = (uint64_t)cut_tile * tile_steps;
+    const uint64_t my_first = split_bound(piece, units, a.split_wgs);
+    const uint32_t my_slab = 2 * piece + (my_first / tile_steps == cut_tile ? 0 : 1);
     float4 *slabs = reinterpret_cast<float4 *>(a.split_scratch) + half * kPassU4;
     constexpr size_t kSlabStride = kSlabU4 * 5 / 4;  // sized for the full form
     {
@@ -496,9 +505,9 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     if (!last) continue;
     // Totals: this part is still in registers, the others come from their slabs.
     for (uint32_t w = w_first; w <= w_last; ++w) {
-      if (w == blockIdx.x) continue;
+      if (w == piece) continue;
       const uint32_t slab =
-          2 * w + (split_bound(w, units, a.split_wgs) / tile_steps == seg_tile ? 0 : 1);
+          2 * w + (split_bound(w, units, a.split_wgs) / tile_steps == cut_tile ? 0 : 1);
       const float4 *src =
           slabs + slab * kSlabStride + (size_t)wave * (BI * 2 * NQ * 4 * 64) + lane;
 #pragma unroll
@@ -623,29 +632,24 @@ hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
     if (e[0] == '3') return launch_shape<false, false, 3>(args, num_tiles, lds_bytes, stream);
   }
 #endif
-  // Short launches (a few tiles per CU or fewer: small blocks, the rectangles
-  // of the staged multi-GPU schedule) run whole rounds of one tile per
-  // workgroup and then the remainder cut into equal pieces over all CUs
-  // (measured: 36 tiles 0.57 -> 0.25 ms, 820 tiles 2.40 -> 2.20 ms, 1128 tiles
-  // 2.92 -> 2.78 ms); under two
-  // tiles per CU the whole launch goes out as pieces.  With
-  // many rounds the dispatcher's own back-filling does as well and the second
-  // launch's boundary costs more than it saves (3160 tiles: +1 %), so long
-  // launches stay whole.
+  // Whole rounds of one tile per workgroup, then the remainder (the tiles that
+  // would leave most CUs idle for a whole tile time) cut into equal pieces of
+  // k-steps over all CUs, in the SAME launch: a CU that finishes its last
+  // whole tile goes straight on to a piece.  Only for launches of fewer than
+  // 8 tiles per CU (small blocks, the rectangles of the staged multi-GPU
+  // schedule): 36 tiles 0.57 -> 0.25 ms, 300 tiles 1.26 -> 0.91 ms, 820 tiles
+  // 2.40 -> 2.15 ms, 2016 tiles 4.54 -> 4.56 ms; with more rounds the
+  // dispatcher's own back-filling leaves a tail of under 3 % and the pieces'
+  // overhead (slabs, extra prologues) costs more than it saves (3160 tiles:
+  // 6.94 -> 7.04 ms).
   const uint32_t wgs = args.split_wgs;
   const uint32_t tile_steps = args.geo.k_words / 8;
   uint64_t whole = num_tiles;
   uint32_t rest = 0;
   if (wgs != 0 && args.split_scratch != nullptr && num_tiles < 8ull * wgs) {
-    if (num_tiles < 2ull * wgs) {
-      // under two tiles per CU: everything as pieces (300 tiles: 0.98 -> 0.91 ms)
-      rest = (uint32_t)num_tiles;
-    } else {
-      rest = (uint32_t)(num_tiles % wgs);
-      // not worth it when the remainder fills most of the chip anyway
-      // (2016 tiles, remainder 224 of 256: 4.50 -> 4.58 ms)
-      if (rest * 2 > wgs) rest = 0;
-    }
+    // under two tiles per CU everything goes out as pieces (300 tiles:
+    // 0.98 -> 0.91 ms); otherwise the remainder after whole rounds
+    rest = num_tiles < 2ull * wgs ? (uint32_t)num_tiles : (uint32_t)(num_tiles % wgs);
     if ((uint64_t)rest * tile_steps < 8ull * wgs) rest = 0;  // too little work to cut up
     whole = num_tiles - rest;
   }
@@ -674,15 +678,38 @@ hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
             (void *)args.split_scratch);
   TiledArgs a = args;
   a.split_tiles = 0;
-  hipError_t e = hipSuccess;
-  if (whole != 0)
-    e = full ? launch_shape<true, false>(a, whole, lds_bytes, stream)
-             : launch_shape<false, false>(a, whole, lds_bytes, stream);
-  if (e != hipSuccess || rest == 0) return e;
-  a.tile_begin = args.tile_begin + whole;
+  a.split_whole = 0;
+  if (rest == 0)
+    return full ? launch_shape<true, false>(a, whole, lds_bytes, stream)
+                : launch_shape<false, false>(a, whole, lds_bytes, stream);
+  // One launch: `head` whole-tile workgroups followed by the wgs pieces of the
+  // remainder, so that CUs finishing their last whole tile go straight on to
+  // pieces (a second launch would wait for the slowest whole tile first).
+  // Anything beyond one launch's block limit goes out whole before it.
+  const uint64_t cap = max_blocks_per_launch(256);
+  uint64_t head = whole;
+  if (cap <= wgs) {
+    // (test hook: a block limit below the piece count) whole tiles on their
+    // own, in as many launches as it takes, then the pieces
+    if (head != 0) {
+      const hipError_t e = full ? launch_shape<true, false>(a, head, lds_bytes, stream)
+                                : launch_shape<false, false>(a, head, lds_bytes, stream);
+      if (e != hipSuccess) return e;
+    }
+    a.tile_begin = args.tile_begin + head;
+    head = 0;
+  } else if (head + wgs > cap) {
+    const uint64_t first = head + wgs - cap;
+    const hipError_t e = full ? launch_shape<true, false>(a, first, lds_bytes, stream)
+                              : launch_shape<false, false>(a, first, lds_bytes, stream);
+    if (e != hipSuccess) return e;
+    a.tile_begin = args.tile_begin + first;
+    head -= first;
+  }
+  a.split_whole = (uint32_t)head;
   a.split_tiles = rest;
-  return full ? launch_shape<true, true>(a, wgs, lds_bytes, stream)
-              : launch_shape<false, true>(a, wgs, lds_bytes, stream);
+  return full ? launch_shape<true, true>(a, head + wgs, lds_bytes, stream)
+              : launch_shape<false, true>(a, head + wgs, lds_bytes, stream);
 }
 
 }  // namespace cuking
