@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   const uint4 *g_rows = a.planes + (uint64_t)tr * kTile;
   const uint4 *g_cols = a.planes + a.geo.col_base + (uint64_t)tc * kTile;
 
-  // Requests piece r (1 KiB) of this wavefront's share of k-step
+  // Requests row r (1 KiB) of this wavefront's share of k-step
   // min(step, last) into LDS buffer `buf`.  Clamping keeps the number of DMAs
   // in flight the same in every iteration, so one counted wait serves the
   // whole loop; the repeats of the last step land in a buffer nobody reads.
@@ -217,9 +217,9 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     if (ABLATE == 1 || ABLATE == 2) return;
     if (step >= num_steps) step = num_steps - 1;
     step += k_first;
-    const uint32_t piece = wave * kPiecesPerWave + r;  // 0..15
-    const uint32_t side = piece >> 3, kg = (piece >> 2) & 1;
-    const uint32_t p = (piece >> 1) & 1, seg = piece & 1;
+    const uint32_t row = wave * kPiecesPerWave + r;  // 1 KiB row of the stage, 0..15
+    const uint32_t side = row >> 3, kg = (row >> 2) & 1;
+    const uint32_t p = (row >> 1) & 1, seg = row & 1;
     // Wave-uniform source row (SGPR pair) + one per-lane byte offset: no
     // per-request address arithmetic in vector registers.
     const uint4 *src = (side ? g_cols : g_rows) +
@@ -241,9 +241,10 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
 #pragma unroll
     for (int r = 0; r < kPiecesPerWave; ++r) issue_piece(step, buf, r);
   };
-  // All but the youngest stage requested so far have landed, for this
-  // wavefront (counted wait) and, after the barrier, for all of them; every
-  // wavefront is also done reading the buffer the next request overwrites.
+  // All but the kStages - 2 youngest stages requested so far have landed, for
+  // this wavefront (counted wait) and, after the barrier, for all of them;
+  // every wavefront is also done reading the buffer the next request
+  // overwrites.
   auto stage_sync = [&]() {
     if (ABLATE == 2) return;
     __builtin_amdgcn_s_waitcnt(kWaitStage);  // vmcnt(kYoungerDmas)
