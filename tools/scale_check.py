@@ -5,6 +5,8 @@ through sub-blocks re-computed by the oracle and size-independent properties.
 
   c2    BASELINE configs[2]: 100k samples x 100k sites, whole triangle
         (4,999,950,000 pairs), threshold 0.0884 (the default, cuking.cu:43)
+  c3    BASELINE configs[3] geometry: 300k samples x 150k sites (11.25 GB bitset),
+        whole triangle (4.5e10 pairs) on ONE GPU, threshold 0.0884; same checks as c2
   c4    BASELINE configs[4] geometry: 734k samples x 200k sites on ONE GPU
         (36.7 GB bitset + as much again for the kernel layout): the last tile
         range, which exercises > 2^32-element indexing, sub-blocks vs oracle;
@@ -44,7 +46,7 @@ def subblock_check(ctx, cuking_amd, pyoracle, bits, res, thr, blocks):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("which", choices=["c2", "c4"])
+    ap.add_argument("which", choices=["c2", "c3", "c4"])
     ap.add_argument("--out", default=str(ROOT / "gpurun_out" / "scale_check.jsonl"))
     ap.add_argument("--whole", action="store_true", help="c4: also run every pair")
     args = ap.parse_args()
@@ -58,6 +60,8 @@ def main():
     report = {"which": args.which}
     if args.which == "c2":
         n, m, thr = 100_000, 100_000, 0.0884
+    elif args.which == "c3":
+        n, m, thr = 300_000, 150_000, 0.0884
     else:
         n, m, thr = 734_000, 200_000, 0.05
     wps = cuking_amd.words_per_sample(m)
@@ -73,7 +77,7 @@ def main():
     sm = cuking_amd.Submatrix(n)
     nf = cohort.num_founders
 
-    if args.which == "c2":
+    if args.which in ("c2", "c3"):
         t0 = time.perf_counter()
         res = ctx.run(sm, wps, bits, thr, max_results=4 << 20)
         dt = time.perf_counter() - t0
@@ -82,7 +86,7 @@ def main():
         report["variant"] = ctx.variant_name()
         report.update(pairs=pairs, wall_s=dt, king_ms=tm.king_ms, prepare_ms=tm.prepare_ms,
                       pairs_per_s=pairs / (tm.king_ms * 1e-3), results=int(len(res)))
-        print(f"[c2] {pairs} pairs: kernel {tm.king_ms:.1f} ms, prepare {tm.prepare_ms:.1f} ms, "
+        print(f"[{args.which}] {pairs} pairs: kernel {tm.king_ms:.1f} ms, prepare {tm.prepare_ms:.1f} ms, "
               f"{report['pairs_per_s']:.3e} pairs/s, {len(res)} records", flush=True)
         got = {(int(r["sample_i"]), int(r["sample_j"])) for r in res}
         want = {(min(a, b), max(a, b)) for a, b, rel in cohort.planted if rel != "half"}
@@ -94,11 +98,12 @@ def main():
                   ((50_000, 50_128), (n - 192, n)), ((nf - 64, nf + 64), (nf - 64, nf + 64))]
         report["pairs_rechecked_by_oracle"] = subblock_check(
             ctx, cuking_amd, pyoracle, bits, res, thr, blocks)
-        # idempotence + the other tile shape
-        ctx.set_option("variant", 1)
-        again = ctx.run(sm, wps, bits, thr, max_results=4 << 20)
-        assert again.tobytes() == res.tobytes()
-        report["variant1_identical"] = True
+        if args.which == "c2":
+            # idempotence + the other tile shape
+            ctx.set_option("variant", 1)
+            again = ctx.run(sm, wps, bits, thr, max_results=4 << 20)
+            assert again.tobytes() == res.tobytes()
+            report["variant1_identical"] = True
     else:
         tiles = ctx.num_tiles(sm)
         tile = ctx.tile_samples()
