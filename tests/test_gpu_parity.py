@@ -388,6 +388,37 @@ def test_matrix_core_float_limit(ctx, oracle, sites, expect_fallback):
     select(ctx, "tiled", 0)
 
 
+@pytest.mark.parametrize("kernel,variant", [("tiled", 5), ("tiled", 0), ("stream", 0)])
+def test_site_position_patterns(ctx, oracle, kernel, variant):
+    """Genotype patterns that single out one site position: the matrix-core
+    kernel expands sites by their position inside a 4-site nibble (position 3 is
+    shifted, the others are masked), inside a 32-site word and inside a
+    4-word quad / 256-site k-step -- every position, every genotype, must land
+    in the right sum."""
+    select(ctx, kernel, variant)
+    m = 700                                   # not a multiple of 32, 64, 128 or 256
+    rows = []
+    for period, phase in [(4, 0), (4, 1), (4, 2), (4, 3), (32, 31), (64, 63), (128, 127),
+                          (256, 255), (256, 0), (7, 3)]:
+        for g_on, g_off in [(1, 0), (2, 0), (0, 2), (1, -1), (-1, 1), (2, 1)]:
+            row = np.full(m, g_off, dtype=np.int8)
+            row[phase::period] = g_on
+            rows.append(row)
+    for g in (0, 1, 2, -1):                   # constant samples
+        rows.append(np.full(m, g, dtype=np.int8))
+    single = np.zeros(m, dtype=np.int8)       # one het site at the very end
+    single[m - 1] = 1
+    rows.append(single)
+    geno = np.stack(rows)
+    bits = oracle.bitset_from_genotypes(geno)
+    n = geno.shape[0]
+    assert check_counts(ctx, oracle, cuking_amd.Submatrix(n), bits) == n * (n - 1) // 2
+    exp, _, _ = oracle.compute(oracle.submatrix(n), bits, 0.1)
+    got = ctx.run(cuking_amd.Submatrix(n), bits.shape[1], ctx.upload_bitset(bits), 0.1)
+    assert got.tobytes() == exp.tobytes()
+    select(ctx, "tiled", 0)
+
+
 def test_options_round_trip(ctx):
     """cuking_ctx_get_option reads back what set_option stored; the default
     kernel variant is the matrix-core one."""
