@@ -70,6 +70,9 @@ def parse_args():
     ap.add_argument("--kernel", default="tiled", choices=["tiled", "stream"])
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--band-rows", type=int, default=-1)
+    ap.add_argument("--counts-mode", type=int, default=-1, choices=[-1, 0, 1],
+                    help="-1 automatic, 0 lean form (4 sums + recount of emitted pairs), "
+                         "1 full form (5 sums)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target CPU-baseline time (0 disables it)")
     ap.add_argument("--cpu-threads", type=int, default=0,
@@ -206,6 +209,8 @@ def main():
         ctx.set_option("variant", args.variant)
     if args.band_rows > 0:
         ctx.set_option("band_rows", args.band_rows)
+    if args.counts_mode >= 0:
+        ctx.set_option("counts_mode", args.counts_mode)
     ctx.timing_enable(True)
 
     # Synthetic cohort, generated on the device (rank 0 owns the "packed
@@ -351,7 +356,10 @@ def main():
                        "king_mfma_kernel" if ctx.get_option("variant") == MFMA_VARIANT else
                        "king_tiled_kernel")
         variant = ctx.get_option("variant")
-        form = "lean" if thr > 0 and thr * thr * 32 * wps >= 1.6 * 1.6 else "full"
+        form = ("full" if args.counts_mode == 1 else "lean" if args.counts_mode == 0 else
+                "lean" if thr > 0 and thr * thr * 32 * wps >= (
+                    1.9 ** 2 if args.kernel == "tiled" and variant == MFMA_VARIANT else 1.6 ** 2)
+                else "full")
         hbm_view = {
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "algorithmic_bytes_per_pair": bpp,

@@ -143,20 +143,25 @@ int effective_variant(const cuking_ctx *ctx, uint32_t words_per_sample) {
   return ctx->variant;
 }
 
-// Which form of the tiled kernel.  The lean form saves one v_bcnt per pair and
-// word but recounts hom/hom sites for every EMITTED pair (measured at 100k
-// sites: +3 ms per 10^6 emitted pairs, against +6.6 ms for the full form at
-// 5x10^7 pairs; break-even near 4 % of the pairs emitted).  For unrelated
-// samples kinship scatters around 0 with a spread ~ 1/sqrt(sites) (at 100k
-// sites 2 % of the pairs exceed 0.005), so the automatic choice is lean iff
-// kin_threshold > 1.6 / sqrt(sites).  Either form gives the same records.
+// Which form of the tiled kernel.  The lean form keeps four sums per pair but
+// recounts hom/hom sites for every EMITTED pair; the full form keeps five sums
+// for every pair.  Measured at 10k x 100k sites: VALU kernels lean 27.8 ms +
+// 3 ms per 10^6 emitted pairs against full 34.4 ms flat; matrix-core kernel
+// lean 7.0 ms + 10 ms per 10^6 emitted pairs against full 10.3 ms + 0.9 ms per
+// 10^6 (two passes over k).  For unrelated samples kinship scatters around 0
+// with a spread ~ 1/sqrt(sites) (at 100k sites 2 % of the pairs exceed 0.005,
+// 0.3 % exceed 0.007), so the automatic choice is lean iff
+// kin_threshold > c / sqrt(sites) with c = 1.6 (VALU) or 1.9 (matrix cores:
+// break-even near 0.7 % of the pairs emitted).  Either form gives the same
+// records.
 bool use_full_counts(const cuking_ctx *ctx, float kin_threshold, bool dense,
                      uint32_t words_per_sample) {
   if (dense || ctx->counts_mode == 1) return true;
   if (ctx->counts_mode == 0) return false;
   if (!(kin_threshold > 0.0f)) return true;
   const double sites = 32.0 * words_per_sample;
-  return (double)kin_threshold * kin_threshold * sites < 1.6 * 1.6;
+  const double c = effective_variant(ctx, words_per_sample) == kMfmaVariant ? 1.9 : 1.6;
+  return (double)kin_threshold * kin_threshold * sites < c * c;
 }
 
 cuking_status bind(cuking_ctx *ctx) {

@@ -157,7 +157,7 @@ cuking_status cuking_ctx_set_kernel(cuking_ctx *ctx, cuking_kernel kernel);
  * (tile-rows per scheduling band, 1..64; env CUKING_AMD_BAND_ROWS) and
  * "counts_mode" (0 = lean: four sums per pair in the main loop, the hom/hom
  * count behind IBS2 recounted only for emitted pairs; 1 = full: all five sums
- * for every pair; -1 = automatic: lean when kin_threshold > 1.6 / sqrt(sites),
+ * for every pair; -1 = automatic: lean when kin_threshold > c / sqrt(sites), c = 1.9 (1.6 for the VALU variants),
  * i.e. when few pairs are expected to pass).  Results do
  * not depend on any of them. */
 cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
