@@ -118,6 +118,26 @@ struct cuking_ctx {
   uint32_t split_wgs = 0;
   std::vector<std::pair<hipStream_t, uint32_t *>> split_scratch;
 
+  // What the plane workspace holds: the block it was converted for and which
+  // 64-sample plane tiles of it have been converted (cuking_compute_king_rect
+  // refuses to read anything else).
+  struct Prepared {
+    bool valid = false;
+    cuking_submatrix sm = {0, 0, 0, 0};
+    uint32_t words_per_sample = 0;
+    int variant = -1;
+    const uint64_t *bits = nullptr;
+    // per 64 plane samples: 0 = not converted, 1 = converted (kernels that
+    // read it, if any, all precede the tail of `ordered_on`), 2 = converted
+    // and read by kernels enqueued since
+    std::vector<uint8_t> tiles;
+    hipStream_t ordered_on = nullptr;
+    bool ordered_valid = false;
+  } prepared;
+  // Streams with pair kernels that may still be reading the workspace, each
+  // with an event to order a later rewrite after them.
+  std::vector<std::pair<hipStream_t, hipEvent_t>> readers;
+
   bool timing = false;
   Timer king_timer, prepare_timer;
 };
@@ -254,13 +274,73 @@ cuking_status check_block(const cuking_submatrix *sm,
   return CUKING_OK;
 }
 
+// A pair kernel that reads the workspace has been enqueued on `stream`.
+void note_reader(cuking_ctx *ctx, hipStream_t stream) {
+  for (auto &r : ctx->readers)
+    if (r.first == stream) return;
+  ctx->readers.emplace_back(stream, nullptr);
+}
+
+// Orders `stream` behind every pair kernel enqueued so far on OTHER streams
+// (same-stream work is ordered anyway): the caller is about to rewrite plane
+// data they may still read.  One context serves one host thread at a time, so
+// "enqueued so far" is everything there is.  Afterwards the tail of `stream`
+// stands for all of them (it stays in the list as their proxy), and no plane
+// tile counts as "being read" any more.
+cuking_status wait_for_readers(cuking_ctx *ctx, hipStream_t stream) {
+  bool failed = false;
+  for (auto &r : ctx->readers) {
+    if (r.first == stream) continue;
+    if (r.second == nullptr &&
+        hipEventCreateWithFlags(&r.second, hipEventDisableTiming) != hipSuccess) {
+      failed = true;
+      break;
+    }
+    if (hipEventRecord(r.second, r.first) != hipSuccess ||
+        hipStreamWaitEvent(stream, r.second, 0) != hipSuccess) {
+      failed = true;  // e.g. a stream the caller has destroyed meanwhile
+      break;
+    }
+  }
+  if (failed) {
+    (void)hipGetLastError();
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  for (auto &r : ctx->readers)
+    if (r.second) (void)hipEventDestroy(r.second);
+  ctx->readers.clear();
+  ctx->readers.emplace_back(stream, nullptr);
+  ctx->prepared.ordered_on = stream;
+  ctx->prepared.ordered_valid = true;
+  for (auto &t : ctx->prepared.tiles)
+    if (t == 2) t = 1;
+  return CUKING_OK;
+}
+
+// Marks plane tiles [begin, end) (units of 64 samples) as read by a kernel
+// that has just been enqueued.
+void mark_read(cuking_ctx *ctx, uint32_t begin, uint32_t end) {
+  std::vector<uint8_t> &t = ctx->prepared.tiles;
+  if (end > t.size()) end = (uint32_t)t.size();
+  for (uint32_t k = begin; k < end; ++k) t[k] = 2;
+}
+
+bool same_block(const cuking_ctx::Prepared &p, const cuking_submatrix &sm,
+                uint32_t words_per_sample, int variant, const uint64_t *bits) {
+  return p.valid && p.sm.i_begin == sm.i_begin && p.sm.i_end == sm.i_end &&
+         p.sm.j_begin == sm.j_begin && p.sm.j_end == sm.j_end &&
+         p.words_per_sample == words_per_sample && p.variant == variant &&
+         p.bits == bits;
+}
+
 // Builds planes + band prefix for `sm` in the context workspace.
 cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
                       uint32_t words_per_sample, const uint64_t *d_bit_sets,
                       hipStream_t stream, PlaneGeometry *geo_out,
                       TileSpace *tiles_out, uint32_t s_tile_begin = 0,
                       uint32_t s_tile_end = 0xFFFFFFFFu) {
-  const TiledVariant &v = tiled_variant(effective_variant(ctx, words_per_sample));
+  const int variant = effective_variant(ctx, words_per_sample);
+  const TiledVariant &v = tiled_variant(variant);
   const PlaneGeometry geo = make_geometry(sm, words_per_sample, v);
   const TileSpace tiles = make_tiles(geo, v, ctx->band_rows);
   *geo_out = geo;
@@ -274,6 +354,7 @@ cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
     if (ctx->planes) HIP_TRY(hipFree(ctx->planes));
     ctx->planes = nullptr;
     ctx->planes_bytes = 0;
+    ctx->prepared.valid = false;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->planes), need));
     ctx->planes_bytes = need;
   }
@@ -303,6 +384,33 @@ cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
   }
 
   if (need == 0) return CUKING_OK;
+  // Book-keeping of what the workspace holds, and ordering against kernels on
+  // other streams that still read what is about to be overwritten.
+  const uint32_t all_tiles = (geo.s_stride + 63) / 64;
+  const uint32_t t_end = s_tile_end < all_tiles ? s_tile_end : all_tiles;
+  cuking_ctx::Prepared &pr = ctx->prepared;
+  // Needs ordering: a conversion for another block while anything may still
+  // read the old one; a repeated conversion of tiles that kernels enqueued
+  // since have read (2); or of tiles whose readers were last ordered behind a
+  // different stream (1).  Fresh tiles of the same block have no readers.
+  const bool other_stream = pr.ordered_valid && pr.ordered_on != stream;
+  bool must_wait = false;
+  if (!same_block(pr, sm, words_per_sample, variant, d_bit_sets)) {
+    must_wait = !ctx->readers.empty();
+    pr.valid = true;
+    pr.sm = sm;
+    pr.words_per_sample = words_per_sample;
+    pr.variant = variant;
+    pr.bits = d_bit_sets;
+    pr.tiles.assign(all_tiles, 0);
+  }
+  for (uint32_t t = s_tile_begin; t < t_end; ++t)
+    must_wait = must_wait || pr.tiles[t] == 2 || (pr.tiles[t] == 1 && other_stream);
+  if (must_wait) {
+    const cuking_status st = wait_for_readers(ctx, stream);
+    if (st != CUKING_OK) return st;
+  }
+  for (uint32_t t = s_tile_begin; t < t_end; ++t) pr.tiles[t] = 1;
   EventPair *ev = nullptr;
   if (ctx->timing) HIP_TRY(ctx->prepare_timer.begin(stream, &ev));
   HIP_TRY(launch_prepare_planes(v.layout, d_bit_sets, words_per_sample, geo, ctx->planes,
@@ -364,6 +472,8 @@ cuking_status run_tiled(cuking_ctx *ctx, const cuking_submatrix &sm,
   HIP_TRY(launch_tiled(effective_variant(ctx, words_per_sample),
                        use_full_counts(ctx, kin_threshold, d_counts != nullptr, words_per_sample), a,
                        tile_end - tile_begin, stream));
+  note_reader(ctx, stream);
+  mark_read(ctx, 0, 0xFFFFFFFFu);
   if (ev) HIP_TRY(hipEventRecord(ev->stop, stream));
   return CUKING_OK;
 }
@@ -552,6 +662,8 @@ void cuking_ctx_destroy(cuking_ctx *ctx) {
   if (ctx->planes) (void)hipFree(ctx->planes);
   if (ctx->band_prefix) (void)hipFree(ctx->band_prefix);
   for (auto &e : ctx->split_scratch) (void)hipFree(e.second);
+  for (auto &r : ctx->readers)
+    if (r.second) (void)hipEventDestroy(r.second);
   ctx->king_timer.destroy();
   ctx->prepare_timer.destroy();
   delete ctx;
@@ -674,7 +786,18 @@ cuking_status cuking_stream_create(cuking_ctx *ctx, void **stream) {
 cuking_status cuking_stream_destroy(cuking_ctx *ctx, void *stream) {
   cuking_status st = bind(ctx);
   if (st != CUKING_OK) return st;
-  if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+  if (stream) {
+    // hipStreamDestroy lets the stream's work finish; nothing may name it later.
+    auto &rs = ctx->readers;
+    for (size_t k = 0; k < rs.size(); ++k)
+      if (rs[k].first == (hipStream_t)stream) {
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        if (rs[k].second) (void)hipEventDestroy(rs[k].second);
+        rs.erase(rs.begin() + k);
+        break;
+      }
+    HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+  }
   return CUKING_OK;
 }
 
@@ -886,9 +1009,12 @@ cuking_status cuking_compute_king_rect(
   const PlaneGeometry geo = make_geometry(*sm, words_per_sample, v);
   const TileSpace tiles = make_tiles(geo, v, ctx->band_rows);
   const size_t need = plane_bytes(geo, v.layout);
-  if (ctx->planes == nullptr || ctx->planes_bytes < need)
+  const int variant = effective_variant(ctx, words_per_sample);
+  if (ctx->planes == nullptr || ctx->planes_bytes < need ||
+      !same_block(ctx->prepared, *sm, words_per_sample, variant, d_bit_sets))
     return fail(CUKING_ERR_FAILED_PRECONDITION,
-                "cuking_prepare_samples() has not been called for this block");
+                "cuking_prepare_samples() has not been called for this block "
+                "(or the workspace has been converted for another one since)");
   uint32_t r0, r1, c0, c1;
   st = tile_span(*sm, v.tile, row_begin, row_end, "row", &r0, &r1);
   if (st != CUKING_OK) return st;
@@ -902,6 +1028,26 @@ cuking_status cuking_compute_king_rect(
                 v.tile);
   const uint32_t stride = row_step / v.tile;
   const uint32_t n_rows = (r1 - r0 + stride - 1) / stride;
+  {
+    // Every sample the rectangle reads must have been converted.
+    const uint32_t per = v.tile / 64;
+    const std::vector<uint8_t> &done = ctx->prepared.tiles;
+    auto converted = [&](uint32_t tile) {
+      for (uint32_t t = tile * per; t < (tile + 1) * per; ++t)
+        if (t >= done.size() || !done[t]) return false;
+      return true;
+    };
+    for (uint32_t r = r0; r < r1; r += stride)
+      if (!converted(r))
+        return fail(CUKING_ERR_FAILED_PRECONDITION,
+                    "row samples from %u on have not been prepared",
+                    sm->i_begin + r * v.tile);
+    for (uint32_t c = c0; c < c1; ++c)
+      if (!converted(c))
+        return fail(CUKING_ERR_FAILED_PRECONDITION,
+                    "column samples from %u on have not been prepared",
+                    sm->i_begin + c * v.tile);
+  }
 
   TiledArgs a;
   a.planes = ctx->planes;
@@ -934,6 +1080,12 @@ cuking_status cuking_compute_king_rect(
   HIP_TRY(launch_tiled(effective_variant(ctx, words_per_sample),
                        use_full_counts(ctx, kin_threshold, false, words_per_sample), a,
                        (uint64_t)n_rows * (c1 - c0), (hipStream_t)stream));
+  note_reader(ctx, (hipStream_t)stream);
+  {
+    const uint32_t per = v.tile / 64;
+    for (uint32_t r = r0; r < r1; r += stride) mark_read(ctx, r * per, (r + 1) * per);
+    mark_read(ctx, c0 * per, c1 * per);
+  }
   if (ev) HIP_TRY(hipEventRecord(ev->stop, (hipStream_t)stream));
   return CUKING_OK;
 }

@@ -6,6 +6,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "king_common.h"
 
 namespace cuking {
@@ -198,6 +200,26 @@ __device__ __forceinline__ void full_epilogue_pair(
                 a.result_overflow);
   }
 }
+
+// "Done once per device" flag for per-function attributes
+// (hipFuncSetAttribute applies to the current device's function object only).
+// Lock-free; a race merely sets the attribute twice.
+struct DeviceOnce {
+  std::atomic<uint64_t> mask[4] = {};  // up to 256 devices
+  static int current() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d & 255;
+  }
+  bool done() const {
+    const int d = current();
+    return (mask[d >> 6].load(std::memory_order_acquire) >> (d & 63)) & 1;
+  }
+  void mark() {
+    const int d = current();
+    mask[d >> 6].fetch_or(1ull << (d & 63), std::memory_order_release);
+  }
+};
 
 // Workgroups per launch: one launch may not exceed 2^32 - 1 threads in x (HIP
 // truncates silently beyond that); tests can lower the cap.

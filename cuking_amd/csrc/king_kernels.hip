@@ -19,6 +19,10 @@
 #include "king_common.h"
 #include "king_device.h"
 
+// The LDS-DMA statements below write M0 and say so in their clobber lists; the
+// compiler notes that it keeps no value of its own there (M0 is reserved).
+#pragma clang diagnostic ignored "-Winline-asm"
+
 namespace cuking {
 
 namespace {
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(TIT *TJT, MINW) void king_tiled_kernel(
             "global_load_lds_dwordx4 %1, off"
             :
             : "s"(lds_addr), "v"(src)
-            : "memory");  // (M0 has no other user in this kernel on gfx950)
+            : "memory", "m0");
       } else {
         __builtin_amdgcn_global_load_lds((global_void_ptr)src, (lds_void_ptr)dst,
                                          16, 0, 0);
@@ -518,13 +522,15 @@ template <int TIT, int TJT, int RI, int RJ, int KC, int KU, int MINW, bool FULL,
 hipError_t launch_variant(const TiledArgs &args, uint64_t num_tiles,
                           uint32_t lds_bytes, hipStream_t stream) {
   auto kernel = king_tiled_kernel<TIT, TJT, RI, RJ, KC, KU, MINW, FULL, ABLATE, PHASED>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // The attribute belongs to the function object of ONE device: a host with
+  // contexts on several GPUs has to set it on each of them.
+  static DeviceOnce attr_set;
+  if (!attr_set.done()) {
     hipError_t e = hipFuncSetAttribute(
         reinterpret_cast<const void *>(kernel),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.mark();
   }
   // One launch may not exceed 2^32 - 1 threads in x (HIP truncates silently
   // beyond that), so long tile ranges go out as several launches.

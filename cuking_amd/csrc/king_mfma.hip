@@ -38,6 +38,10 @@
 #include "king_common.h"
 #include "king_device.h"
 
+// The LDS-DMA statements below write M0 and say so in their clobber lists; the
+// compiler notes that it keeps no value of its own there (M0 is reserved).
+#pragma clang diagnostic ignored "-Winline-asm"
+
 #ifndef CUKING_MFMA_STAGES
 #define CUKING_MFMA_STAGES 6
 #endif
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
         "global_load_lds_dwordx4 %1, %2"
         :
         : "s"(lds_addr), "v"(lane16), "s"(src)
-        : "memory");
+        : "memory", "m0");
   };
   auto issue_stage = [&](uint32_t step, uint32_t buf) {
 #pragma unroll
@@ -586,13 +590,13 @@ template <bool FULL, bool SPLIT, int ABLATE = 0>
 hipError_t launch_shape(const TiledArgs &args, uint64_t num_blocks,
                         uint32_t lds_bytes, hipStream_t stream) {
   auto kernel = king_mfma_kernel<FULL, SPLIT, ABLATE>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;  // per device, see king_device.h
+  if (!attr_set.done()) {
     hipError_t e = hipFuncSetAttribute(
         reinterpret_cast<const void *>(kernel),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.mark();
   }
   if (SPLIT) {  // one launch of split_wgs workgroups
     kernel<<<dim3((uint32_t)num_blocks), dim3(256), lds_bytes, stream>>>(args);

@@ -4,7 +4,8 @@ torch.distributed; backend "nccl" = RCCL over xGMI, "gloo" for CPU tests).
 Replaces the reference's multi-VM fan-out (cloud_batch_submit.py:45,73;
 README.md:94-102), where each of k(k+1)/2 VMs re-reads the whole input and
 computes one block.  Here the block's pair space is cut into the tiled
-kernel's 64x64-sample tiles (thousands of them), every rank takes one
+kernel's square sample tiles (128 x 128 for the default matrix-core variant,
+`cuking_tile_samples`; thousands of them), every rank takes one
 contiguous, equally sized range of the tile enumeration, and the data path has
 exactly two exchange steps:
 
@@ -12,6 +13,13 @@ exactly two exchange steps:
        (N * words_per_sample * 8 bytes, once)
     2. gather of the thresholded KingResult records on rank 0
        (all_gather of the counts, then a padded gather of count x 24 bytes)
+
+A rank whose local work fails (an exception from the kernel call, an
+out-of-memory, ...) must not leave the others waiting inside the gather until
+the communicator times out: before step 2 every rank contributes a status word
+(``agree_on_status``; in the pipelined gather it rides in the header row of the
+one all-gather), and a failure anywhere raises on every rank -- the original
+exception on the rank that had it, ``RemoteRankError`` on the others.
 
 Every tile costs the same (diagonal tiles are evaluated in full and masked at
 emit), so equal tile counts are equal work.
@@ -39,6 +47,35 @@ from typing import Callable, List, Optional, Tuple
 import numpy as np
 
 from .api import KING_RESULT_DTYPE, ResourceExhaustedError, sort_results
+
+
+class RemoteRankError(RuntimeError):
+    """Another rank of the job failed; this rank stops with it."""
+
+
+def agree_on_status(error: Optional[BaseException] = None, group=None, device=None) -> None:
+    """Every rank calls this after its local work with the exception it caught
+    (or None).  One all-reduce of a world-sized one-hot vector; if any rank
+    reports a failure every rank raises: its own exception where there is one,
+    RemoteRankError naming the failed ranks elsewhere.  No-op without a process
+    group."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        if error is not None:
+            raise error
+        return
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = "cpu" if dist.get_backend(group) == "gloo" or device is None else device
+    flags = torch.zeros(world, dtype=torch.int32, device=dev)
+    if error is not None:
+        flags[rank] = 1
+    dist.all_reduce(flags, group=group)
+    failed = [r for r, f in enumerate(flags.tolist()) if f]
+    if error is not None:
+        raise error
+    if failed:
+        raise RemoteRankError(f"rank(s) {failed} failed; rank {rank} stops with them")
 
 
 def tile_partition(num_tiles: int, world_size: int) -> List[Tuple[int, int]]:
@@ -154,34 +191,52 @@ class PipelinedGather:
     def __init__(self, dst: int = 0, group=None, fast_rows: int = 8192):
         import torch
         self.dst, self.group, self.fast_rows = dst, group, fast_rows
-        self.side = torch.cuda.Stream()
+        # (host tensors + gloo in the CPU tests: no streams)
+        self.side = torch.cuda.Stream() if torch.cuda.is_available() else None
 
-    def begin(self, local, index_flag):
+    def begin(self, local, index_flag, error: Optional[BaseException] = None):
+        """``error``: the exception this rank's pass raised, if any -- it still
+        takes part in the all-gather (header word 2 = 1) so that ``finish``
+        raises on every rank instead of the others waiting for a rank that has
+        gone."""
         import torch
         import torch.distributed as dist
         world = dist.get_world_size(self.group)
         rows = min(self.fast_rows, local.shape[0])
         block = torch.empty((rows + 1, 6), dtype=torch.int32, device=local.device)
         block[0, :2] = index_flag
+        block[0, 2] = 0 if error is None else 1
         block[1:] = local[:rows]
         parts = [torch.empty_like(block) for _ in range(world)]
         work = dist.all_gather(parts, block, group=self.group, async_op=True)
-        return {"local": local, "rows": rows, "parts": parts, "work": work, "block": block}
+        return {"local": local, "rows": rows, "parts": parts, "work": work, "block": block,
+                "error": error}
 
     def finish(self, h):
         import torch
         import torch.distributed as dist
         rank = dist.get_rank(self.group)
         world = dist.get_world_size(self.group)
-        with torch.cuda.stream(self.side):
-            h["work"].wait()                      # side stream waits for the all-gather
+        if self.side is None:
+            h["work"].wait()
             blocks = torch.stack(h["parts"])
-            host = (blocks if rank == self.dst else blocks[:, 0, :2]).to("cpu", non_blocking=True)
-            done = torch.cuda.Event()
-            done.record(self.side)
-        done.synchronize()                        # not the compute stream
+            host = blocks if rank == self.dst else blocks[:, 0, :3]
+        else:
+            with torch.cuda.stream(self.side):
+                h["work"].wait()                  # side stream waits for the all-gather
+                blocks = torch.stack(h["parts"])
+                host = (blocks if rank == self.dst else blocks[:, 0, :3]).to(
+                    "cpu", non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(self.side)
+            done.synchronize()                    # not the compute stream
         host = host.numpy()
-        heads = host[:, 0, :2] if rank == self.dst else host
+        heads = host[:, 0, :3] if rank == self.dst else host
+        if h["error"] is not None:
+            raise h["error"]
+        if heads[:, 2].any():
+            failed = [r for r in range(world) if heads[r, 2]]
+            raise RemoteRankError(f"rank(s) {failed} failed; rank {rank} stops with them")
         counts = [int(c) for c in heads[:, 0]]
         if heads[:, 1].any():
             raise ResourceExhaustedError(
@@ -212,7 +267,12 @@ def all_pairs_king(compute_tiles: Callable, num_tiles: int, bit_sets,
     if broadcast:
         broadcast_bitset(bit_sets, src=src, group=group)
     begin, end = tile_partition(num_tiles, world)[rank]
-    out = compute_tiles(bit_sets, begin, end)
+    out, error = None, None
+    try:
+        out = compute_tiles(bit_sets, begin, end)
+    except Exception as e:  # noqa: BLE001 - re-raised by agree_on_status, on every rank
+        error = e
+    agree_on_status(error, group=group, device=getattr(bit_sets, "device", None))
     if len(out) == 2:
         return gather_results_device(out[0], out[1], dst=dst, group=group), (begin, end)
     local, count, overflow = out
@@ -284,16 +344,29 @@ def all_pairs_king_staged(ops, num_samples: int, tile: int, bit_sets,
     # All chunk broadcasts are enqueued up front; they complete in order.
     works = [dist.broadcast(bit_sets[c0:c1], src=src, group=group, async_op=True)
              for (c0, c1), _ in steps] if use_dist else []
+    error = None
     for k, ((c0, c1), rect) in enumerate(steps):
         if use_dist and rank != src:
             works[k].wait()        # nccl: the current stream waits, not the host
-        if rect is None:
-            continue               # this rank never reads these samples
-        ops.prepare(c0, c1)
-        ops.compute_rect(*rect)
+        if rect is None or error is not None:
+            continue               # never reads these samples / already failed:
+        try:                       # keep taking part in the broadcasts
+            ops.prepare(c0, c1)
+            ops.compute_rect(*rect)
+        except Exception as e:  # noqa: BLE001 - raised on every rank below
+            error = e
     for w in works:                # the source's sends, too, before reuse
         w.wait()
-    local, count, overflow = ops.finish()
+    local = count = overflow = None
+    if error is None:
+        try:
+            local, count, overflow = ops.finish()
+        except Exception as e:  # noqa: BLE001
+            error = e
+    if use_dist:
+        agree_on_status(error, group=group, device=getattr(bit_sets, "device", None))
+    elif error is not None:
+        raise error
     if not use_dist:
         if overflow:
             raise ResourceExhaustedError(

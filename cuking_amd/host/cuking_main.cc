@@ -297,6 +297,10 @@ Status Run(const Flags &flags) {
                                                 reinterpret_cast<void **>(&d_pack_status))));
     RETURN_IF_ERROR(FromAbi(
         cuking_memset_async(buf.ctx, d_pack_status, 0, sizeof(uint32_t), nullptr)));
+    // The packers' streams are non-blocking, i.e. NOT ordered behind the null
+    // stream: the all-ones fill of the bitset (tens of ms at cohort scale) and
+    // the zeroed status word must be complete before the first pack kernel.
+    RETURN_IF_ERROR(FromAbi(cuking_stream_synchronize(buf.ctx, nullptr)));
   }
   const std::string pack_error = cuking_host::ParallelFor(
       flags.num_reader_threads, 0, input_files.size(), [&](size_t f) -> std::string {

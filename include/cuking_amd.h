@@ -178,7 +178,26 @@ const char *cuking_variant_name(int variant);
  * d_result_index and d_result_overflow are NOT reset by the call (the caller
  * zeroes them, like cuking.cu:721-722), so several calls may append to one
  * buffer.  Record order is unspecified (sort afterwards, :761-765).
- * Asynchronous on `stream`. */
+ * Asynchronous on `stream`.
+ *
+ * Numerics contract.  The sums, IBS0/1/2 and het counts are exact integers for
+ * any width.  kin = fl32(0.5f + fl32(num / den)) with the IEEE-correct divide.
+ * Below 2^22 sites (4,194,304; every BASELINE config is <= 200,000) every
+ * partial sum of num = 2 bh - 4 opp - hi - hj is an integer below 2^24, so the
+ * value is the same for every association order and every FMA contraction a
+ * compiler may apply to cuking.cu:291-294: bit-exact against the reference.
+ * From 2^22 sites on, this library evaluates the expression left to right
+ * with one float32 rounding per operation (no contraction); a reference build
+ * that fuses multiply-adds may differ there in the last bit.  The matrix-core
+ * variant counts in float32 and serves bitsets up to 2^24 sites; wider ones
+ * take a VALU variant automatically (same records).
+ *
+ * Streams.  The compute / prepare entry points convert the bitset into a
+ * kernel-internal layout held by the context.  Calls on different streams of
+ * one context are ordered by the library where a conversion would overwrite
+ * what an earlier call's kernel may still read (event waits, no host
+ * synchronisation); concurrent kernels only arise from
+ * cuking_compute_king_rect launches on different streams. */
 cuking_status cuking_compute_king(cuking_ctx *ctx, const cuking_submatrix *sm,
                                   uint32_t words_per_sample,
                                   const uint64_t *d_bit_sets,

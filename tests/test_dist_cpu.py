@@ -253,3 +253,76 @@ def test_device_side_gather_matches_host_gather(tmp_path, world):
     out = tmp_path / "res"
     mp.spawn(_device_gather_worker, args=(world, _free_port(), str(out)), nprocs=world, join=True)
     assert all(Path(f"{out}.{r}").read_text() == "ok" for r in range(world))
+
+
+def _failure_worker(rank, world, port, mode, out_path):
+    """Rank `world - 1` fails in its local work; nobody may hang in a collective."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cuking_amd.dist import (PipelinedGather, RemoteRankError, all_pairs_king,
+                                 all_pairs_king_staged)
+    bad = rank == world - 1
+    bits = torch.zeros((200, 4), dtype=torch.int64)
+    local = torch.zeros((16, 6), dtype=torch.int32)
+    outcome = "returned"
+    try:
+        if mode == "simple":
+            def compute_tiles(b, begin, end):
+                if bad:
+                    raise RuntimeError("injected kernel failure")
+                return local, 0, 0
+            all_pairs_king(compute_tiles, 10, bits)
+        elif mode == "staged":
+            class Ops:
+                def begin(self): pass
+                def prepare(self, s0, s1):
+                    if bad and s0 > 0:
+                        raise RuntimeError("injected kernel failure")
+                def compute_rect(self, rows, cols): pass
+                def finish(self): return local, 0, 0
+            all_pairs_king_staged(Ops(), 200, 64, bits, num_chunks=3)
+        else:
+            pipe = PipelinedGather(fast_rows=8)
+            flag = torch.tensor([2, 0], dtype=torch.int32)
+            err = RuntimeError("injected kernel failure") if bad else None
+            pipe.finish(pipe.begin(local, flag, error=err))
+    except RemoteRankError as e:
+        outcome = f"remote:{e}"
+    except RuntimeError as e:
+        outcome = f"own:{e}"
+    Path(f"{out_path}.{rank}").write_text(outcome)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["simple", "staged", "pipelined"])
+@pytest.mark.timeout(120)
+def test_failure_on_one_rank_raises_on_all(tmp_path, mode):
+    """SURVEY section 5 'per-rank error -> abort all ranks': an exception on one
+    rank before the gather must surface on every rank, promptly."""
+    world = 3
+    out = tmp_path / "res"
+    mp.spawn(_failure_worker, args=(world, _free_port(), mode, str(out)), nprocs=world,
+             join=True)
+    got = [Path(f"{out}.{r}").read_text() for r in range(world)]
+    assert got[world - 1] == "own:injected kernel failure"
+    for r in range(world - 1):
+        assert got[r].startswith("remote:") and f"[{world - 1}]" in got[r], got
+
+
+def _status_ok_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cuking_amd.dist import PipelinedGather, agree_on_status
+    agree_on_status(None)                                  # nobody failed: returns
+    pipe = PipelinedGather(fast_rows=8)
+    local = torch.arange(96, dtype=torch.int32).reshape(16, 6) + 1000 * rank
+    recs = pipe.finish(pipe.begin(local, torch.tensor([3 + rank, 0], dtype=torch.int32)))
+    ok = (recs is None) if rank else (len(recs) == sum(3 + r for r in range(world)))
+    Path(f"{out_path}.{rank}").write_text("ok" if ok else "bad")
+    dist.destroy_process_group()
+
+
+def test_pipelined_gather_on_host_tensors(tmp_path):
+    out = tmp_path / "res"
+    mp.spawn(_status_ok_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    assert all(Path(f"{out}.{r}").read_text() == "ok" for r in range(2))
