@@ -2,35 +2,50 @@
 """All-pairs KING throughput on MI355X (BASELINE.json metric: sample-pairs/s +
 achieved HBM GB/s vs roofline).
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--config c1|c2|c3|c4|weak]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A step = one pass of the hot path over one synthetic cohort whose packed
 bitset is already resident in HBM (reference layout, cuking.cu:507-523):
 layout preparation + the pair kernel (matrix-core variant by default) over
-every (i < j) pair + thresholded append of KingResult records.  For N > 1 a
-step is the sharded pass of cuking_amd/dist.py: every rank holds the bitset
-(as every shard of the reference reads the whole input itself), evaluates its
-range of pair-space tiles, and the records are gathered on rank 0 -- the only
-collective; the gather of one pass runs behind the kernel of the next.  --dist-mode staged / simple instead start from a bitset that only
-rank 0 holds and count its RCCL broadcast in the step.
+every (i < j) pair + thresholded append of KingResult records.
 
-N = 1 workload: BASELINE.json configs[1], 10k samples x 100k sites,
-kin-threshold 0.05.  N > 1 (weak scaling): the same sites and threshold with
-round(10000 * sqrt(N)) samples, i.e. the same number of pairs per GPU.
+Workloads (BASELINE.json configs):
+  N = 1   configs[1], 10k samples x 100k sites, kin-threshold 0.05 -- the
+          headline `value`.  The same JSON line carries, under
+          `other_configs`, configs[2] (100k x 100k, the largest single-GPU
+          config) and configs[3]'s cohort (300k x 150k) on this ONE GPU, so
+          that a multi-GPU run of configs[3] has its single-GPU figure.
+  N > 1   configs[3], 300k samples x 150k sites, STRONG scaling: the whole
+          4.5e10-pair triangle is cut into N equal contiguous ranges of
+          pair-space tiles (cuking_amd/dist.py), every rank holds the bitset
+          (as every shard of the reference reads the whole input itself),
+          and the records are gathered on rank 0 -- the only collective in
+          the timed steps; the gather of one pass runs behind the kernel of
+          the next.  After the timed region the same job is run ONCE more
+          from a bitset that only rank 0 holds, in both broadcast forms
+          (chunked + overlapped, and broadcast-then-compute): `with_broadcast`.
+  --config weak reproduces round 1's weak-scaling series (10000 sqrt(N)
+  samples x 100k sites).
 
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
-import argparse
-import json
-import math
 import os
-import sys
-import time
-from pathlib import Path
+
+# The CPU baseline's OpenMP threads are pinned (read by libgomp when it is
+# first loaded, i.e. by `import torch`).
+os.environ.setdefault("OMP_PLACES", "cores")
+os.environ.setdefault("OMP_PROC_BIND", "close")
+
+import argparse  # noqa: E402
+import json  # noqa: E402
+import math  # noqa: E402
+import sys  # noqa: E402
+import time  # noqa: E402
+from pathlib import Path  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
@@ -39,8 +54,7 @@ if str(ROOT) not in sys.path:
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 # MI355X_MICROARCH.md, matrix cores: FP4 (block-scaled f8f6f4 MFMA) ~10 PF dense.
 MFMA_FP4_PEAK_TFLOPS = 10000.0
-# king_mfma.hip: five plane products per pair and site (opp = A.R + R.A, bh,
-# hi, hj), one multiply-add = 2 FLOP.
+# king_mfma.hip: plane products per pair and site, one multiply-add = 2 FLOP.
 MFMA_MACS_PER_PAIR_SITE = {"lean": 5, "full": 6}
 MFMA_VARIANT = 5
 NOMINAL_CLOCK_HZ = 2.4e9        # MI355X_MICROARCH.md: max clock
@@ -50,12 +64,22 @@ NUM_SIMDS = 256 * 4
 VALU_OPS_PER_PAIR_WORD = {"lean": 9, "full": 10}
 # VALU issue floor, measured on MI355X (tools/micro/king_step.hip, valu_phase.hip;
 # profiles/r01_valu_microbench.txt), cycles per wave64 instruction per SIMD:
-# v_and 2.07, v_bitop3 2.37, v_bcnt_u32_b32 4.19 when each kind runs alone.  The
-# phased kernel (logic phase / popcount phase, waves of a workgroup paired per
-# SIMD) is priced against the SUM of its parts: 4 x 2.07 + 2.37 + n_bcnt x 4.19.
-# (Unsynchronised waves mixing the kinds cost ~4.06 per instruction: 36.5 / 40.7.)
+# v_and 2.07, v_bitop3 2.37, v_bcnt_u32_b32 4.19 when each kind runs alone.
 VALU_FLOOR_CYCLES_PER_PAIR_WORD = {"lean": 4 * 2.07 + 2.37 + 4 * 4.19,
                                    "full": 4 * 2.07 + 2.37 + 5 * 4.19}
+
+CONFIGS = {
+    "c1": dict(samples=10_000, sites=100_000, thr=0.05,
+               name="BASELINE configs[1]: 10k samples x 100k sites, kin-threshold 0.05"),
+    "c2": dict(samples=100_000, sites=100_000, thr=0.0884,
+               name="BASELINE configs[2]: 100k samples x 100k sites, kin-threshold 0.0884 "
+                    "(the reference's default, cuking.cu:43)"),
+    "c3": dict(samples=300_000, sites=150_000, thr=0.0884,
+               name="BASELINE configs[3]: 300k samples x 150k sites, kin-threshold 0.0884"),
+    "c4": dict(samples=734_000, sites=200_000, thr=0.05,
+               name="BASELINE configs[4]: 734k samples x 200k sites, kin-threshold 0.05, "
+                    "IBS0/1/2 emitted"),
+}
 
 
 def parse_args():
@@ -63,9 +87,15 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="", choices=["", "c1", "c2", "c3", "c4", "weak"],
+                    help="workload; default c1 at N=1, c3 (strong scaling) at N>1")
+    ap.add_argument("--extra-configs", default=None,
+                    help="N=1: comma list of further configs measured after the headline "
+                         "and reported under other_configs (default c2,c3 with --config c1; "
+                         "'none' disables)")
     ap.add_argument("--samples", type=int, default=0, help="override N samples")
-    ap.add_argument("--sites", type=int, default=100000)
-    ap.add_argument("--kin-threshold", type=float, default=0.05)
+    ap.add_argument("--sites", type=int, default=0, help="override the site count")
+    ap.add_argument("--kin-threshold", type=float, default=None)
     ap.add_argument("--max-results", type=int, default=1 << 20)
     ap.add_argument("--kernel", default="tiled", choices=["tiled", "stream"])
     ap.add_argument("--variant", type=int, default=-1)
@@ -79,24 +109,40 @@ def parse_args():
                     help="OpenMP threads of the CPU baseline (0 = min(16, available))")
     ap.add_argument("--dist-mode", default="resident",
                     choices=["resident", "staged", "simple"],
-                    help="N>1: the packed bitset is resident on every GPU before the "
-                         "timed region, like the reference's shards that each read the "
-                         "input themselves (resident, default); or rank 0 owns it and "
-                         "every step distributes it first: chunked broadcast overlapped "
+                    help="N>1, timed steps: the packed bitset is resident on every GPU "
+                         "before the timed region, like the reference's shards that each "
+                         "read the input themselves (resident, default); or rank 0 owns it "
+                         "and every step distributes it first: chunked broadcast overlapped "
                          "with compute (staged) / broadcast then compute (simple)")
+    ap.add_argument("--no-broadcast-pass", action="store_true",
+                    help="N>1: skip the extra broadcast-inclusive passes after the timed region")
     ap.add_argument("--chunks", type=int, default=8, help="broadcast chunks (staged)")
     ap.add_argument("--streams", type=int, default=3, help="side streams for rectangle launches")
     ap.add_argument("--no-check", action="store_true",
                     help="skip the planted-relatives check (timing-only tuning kernels)")
+    ap.add_argument("--no-clock-pass", action="store_true",
+                    help="skip the sustained-clock pass after the timed region")
     ap.add_argument("--seed", type=int, default=20240229)
     return ap.parse_args()
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def cpu_baseline(host_bits_fn, wps, gpu_records, thr, target_seconds, max_samples,
                  cpu_threads=0):
-    """Times the oracle (oracle/king_oracle.c, -march=native, OpenMP over rows)
-    on a leading sub-block of the SAME cohort, and checks the GPU's records for
-    that sub-block against it.  Test-infrastructure use only."""
+    """Times the oracle (oracle/king_oracle.c, -march=native, OpenMP over rows,
+    threads pinned to cores) on a leading sub-block of the SAME cohort, and
+    checks the GPU's records for that sub-block against it.
+    Test-infrastructure use only."""
+    import ctypes as C
     import tempfile
     import numpy as np
     from oracle import pyoracle
@@ -105,10 +151,8 @@ def cpu_baseline(host_bits_fn, wps, gpu_records, thr, target_seconds, max_sample
     threads = cpu_threads or min(16, len(os.sched_getaffinity(0)))
     out_dir = Path(tempfile.mkdtemp(prefix="cuking_oracle_"))
     lib = pyoracle.load(native=True, out_dir=out_dir)
-    os.environ.setdefault("OMP_PROC_BIND", "true")
 
     def run(s):
-        import ctypes as C
         bits = host_bits_fn(s)
         sm = pyoracle.submatrix(s)
         res = np.zeros(1 << 20, dtype=pyoracle.RESULT_DTYPE)
@@ -122,7 +166,8 @@ def cpu_baseline(host_bits_fn, wps, gpu_records, thr, target_seconds, max_sample
         lib.orc_sort(res.ctypes.data_as(C.c_void_p), res.size)
         return s * (s - 1) // 2, dt, res
 
-    pairs, dt, _ = run(256)                      # calibration
+    run(256)
+    pairs, dt, _ = run(1024)                     # calibration (threads warm)
     rate = pairs / dt
     s = int(min(max_samples, max(256, math.sqrt(2 * rate * target_seconds))))
     pairs, dt, res = run(s)
@@ -130,34 +175,178 @@ def cpu_baseline(host_bits_fn, wps, gpu_records, thr, target_seconds, max_sample
     if sel.tobytes() != res.tobytes():
         raise SystemExit(f"PARITY FAILURE: GPU records for the first {s} samples "
                          "differ from the CPU oracle")
-    cpu_model = "unknown CPU"
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                cpu_model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
     return {"value": pairs / dt, "unit": "sample-pairs/s", "cores": threads,
             "kind": "port",
+            "omp": {"OMP_PLACES": os.environ.get("OMP_PLACES"),
+                    "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"),
+                    "threads": threads,
+                    "hardware_threads_visible": len(os.sched_getaffinity(0))},
             "sample": f"first {s} samples ({pairs} pairs) of the same cohort, "
-                      f"{dt:.1f} s, OpenMP x{threads} on {cpu_model} "
-                      f"({len(os.sched_getaffinity(0))} hardware threads visible), "
-                      "-O3 -march=native; records checked equal to the GPU's"}
+                      f"{dt:.1f} s, OpenMP x{threads} pinned (OMP_PLACES=cores) on "
+                      f"{cpu_model()}, -O3 -march=native; records checked equal to the GPU's"}
 
 
-def load_traffic(workload_key, kernel_name):
-    """HBM bytes per launch from committed rocprofv3 PMC passes (profiles/),
-    corrected as MI355X_MICROARCH.md prescribes; None if not measured for this
-    workload and kernel."""
+def committed_profile(workload_key, kernel_name):
+    """Figures from committed rocprofv3 passes of this command (profiles/): HBM
+    bytes per launch (PMC, corrected as MI355X_MICROARCH.md prescribes) and the
+    kernel's average duration in the --kernel-trace --stats pass.  They are
+    CONSTANTS read from files, not measured by this run -- the JSON says so."""
     p = ROOT / "profiles" / "hbm_traffic.json"
     if not p.exists():
-        return None
+        return {}
     try:
-        entry = json.loads(p.read_text()).get(f"{workload_key}:{kernel_name}", {})
-        return entry.get("traffic_bytes_per_launch")
+        return json.loads(p.read_text()).get(f"{workload_key}:{kernel_name}", {})
     except Exception:
-        return None
+        return {}
+
+
+def counts_form(args, thr, wps, variant):
+    if args.counts_mode == 1:
+        return "full"
+    if args.counts_mode == 0:
+        return "lean"
+    c = 1.9 if args.kernel == "tiled" and variant == MFMA_VARIANT else 1.6
+    return "lean" if thr > 0 and thr * thr * 32 * wps >= c * c else "full"
+
+
+def roofline_block(args, ctx, *, launch_pairs, sites, wps, thr, king_ms, prepare_ms,
+                   launches, workload_key, clock_mhz, use_profile=True):
+    """The `roofline` object for the pair kernel: algorithmic work of one launch
+    / its average duration measured with HIP events on the launching stream."""
+    import cuking_amd
+    bpp = cuking_amd.bytes_per_pair(wps)
+    variant = ctx.get_option("variant")
+    mfma = args.kernel == "tiled" and variant == MFMA_VARIANT and 32 * wps <= (1 << 24)
+    kernel_name = ("king_stream_kernel" if args.kernel == "stream" else
+                   "king_mfma_kernel" if mfma else "king_tiled_kernel")
+    form = counts_form(args, thr, wps, variant)
+    achieved = launch_pairs * bpp / (king_ms * 1e-3) / 1e9 if king_ms > 0 else 0.0
+    hbm_view = {
+        "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBPS, "algorithmic_bytes_per_pair": bpp,
+        "note": "algorithmic bytes (2 samples x words_per_sample x 8 B per pair, "
+                "SURVEY.md 8d) / measured kernel time; operands are re-used from LDS and "
+                "registers, so this exceeds 1.0 of HBM peak by design",
+    }
+    prof = committed_profile(workload_key, kernel_name) if use_profile else {}
+    common = {
+        "traffic": prof.get("traffic_bytes_per_launch"),
+        "traffic_source": (f"committed rocprofv3 --pmc passes of this command "
+                           f"({prof.get('source', 'profiles/hbm_traffic.json')}); a constant "
+                           "read from the file, NOT measured by this run"
+                           if prof.get("traffic_bytes_per_launch") is not None else
+                           "not measured for this workload"),
+        "kernel": kernel_name, "kernel_ms": king_ms,
+        "kernel_ms_source": "HIP events around every launch on its stream, this run",
+        "kernel_ms_rocprof": prof.get("rocprof_avg_ms"),
+        "kernel_ms_rocprof_source": (prof.get("rocprof_source") if prof.get("rocprof_avg_ms")
+                                     else None),
+        "launches": launches, "prepare_ms": prepare_ms,
+        "sustained_clock_mhz": clock_mhz,
+        "sustained_clock_source": ("in-kernel s_memtime / s_memrealtime probe during a "
+                                   "separate pass of the same steps (cuking_clock_probe)"
+                                   if clock_mhz else None),
+    }
+    if mfma:
+        macs = MFMA_MACS_PER_PAIR_SITE[form]
+        tflops = (launch_pairs * sites * macs * 2 / (king_ms * 1e-3) / 1e12) if king_ms > 0 else 0.0
+        return {
+            "bound": "mfma", "achieved": tflops, "peak": MFMA_FP4_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": tflops / MFMA_FP4_PEAK_TFLOPS, **common,
+            "form": form, "macs_per_pair_site": macs,
+            "note": "fp4 (E2M1) v_mfma_f32_32x32x64_f8f6f4, exact integer sums in f32; "
+                    "algorithmic FLOP = pairs x sites x plane products x 2 (padding of "
+                    "tiles and of the last k-step not counted); peak = dense FP4 at the "
+                    "nominal 2.4 GHz, the chip holds less under this load "
+                    "(sustained_clock_mhz)",
+            "hbm": hbm_view,
+        }
+    roofline = {"bound": "hbm", **hbm_view, **common}
+    cyc = (king_ms * 1e-3 * NOMINAL_CLOCK_HZ * NUM_SIMDS * 64 /
+           (launch_pairs * wps)) if king_ms > 0 else 0.0
+    floor = VALU_FLOOR_CYCLES_PER_PAIR_WORD[form]
+    roofline["valu"] = {
+        "form": form, "ops_per_pair_word": VALU_OPS_PER_PAIR_WORD[form],
+        "achieved_cycles_per_pair_word": cyc, "floor_cycles_per_pair_word": floor,
+        "frac": floor / cyc if cyc else 0.0,
+    }
+    return roofline
+
+
+def records_of(results, count):
+    import numpy as np
+    import cuking_amd
+    recs = results[:count].cpu().numpy().view(np.uint32).reshape(-1).view(
+        cuking_amd.KING_RESULT_DTYPE).copy()
+    return cuking_amd.sort_results(recs)
+
+
+def check_planted(recs, cohort, thr, no_check):
+    """Every planted relative the threshold admits must be reported (half
+    siblings sit near 0.125: only asked for below 0.06)."""
+    if no_check:
+        return
+    got = {(int(r["sample_i"]), int(r["sample_j"])) for r in recs}
+    kinds = ("dup", "po", "sib", "half") if thr <= 0.06 else ("dup", "po", "sib")
+    missing = [p for p in cohort.planted
+               if p[2] in kinds and (min(p[0], p[1]), max(p[0], p[1])) not in got]
+    if missing:
+        raise SystemExit(f"{len(missing)} planted relatives not reported")
+
+
+def single_gpu_workload(args, ctx, n, m, thr, steps, warmup, local_rank, clock_pass=True):
+    """`steps` timed passes over a resident cohort on one GPU.  Returns the
+    measurements plus the records of the last pass and the device bitset."""
+    import torch
+    import cuking_amd
+    from cuking_amd.synth import cohort_to_device, plan_cohort
+    dev = f"cuda:{local_rank}"
+    wps = cuking_amd.words_per_sample(m)
+    sm = cuking_amd.Submatrix(n)
+    pairs = sm.NumPairs()
+    cohort = plan_cohort(n, args.seed)
+    kind, pa, pb = cohort_to_device(cohort, local_rank)
+    bits = ctx.synth_bitset(args.seed, kind, pa, pb, 0, n, m)
+    results = torch.zeros((args.max_results, 6), dtype=torch.int32, device=dev)
+    index_flag = torch.zeros(2, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        index_flag.zero_()
+        ctx.compute_king(sm, wps, bits, thr, args.max_results, results,
+                         index_flag[0:1], index_flag[1:2])
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    ctx.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timing = ctx.timing_collect()
+    count, ovf = index_flag.tolist()
+    if ovf:
+        raise SystemExit("result overflow: raise --max-results")
+    recs = records_of(results, count)
+    check_planted(recs, cohort, thr, args.no_check)
+
+    clock = None
+    if clock_pass and not args.no_clock_pass:
+        # the same steps once more with the one-wave clock probe beside them
+        # (it holds a wave slot of one CU, so it stays out of the timed region)
+        span_us = max(2000, int(0.8 * elapsed * 1e6))
+        read = ctx.clock_probe(span_us, torch.cuda.Stream())
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        clock = read()
+    return dict(n=n, m=m, thr=thr, wps=wps, pairs=pairs, elapsed=elapsed, steps=steps,
+                king_ms=timing.king_ms / max(timing.king_launches, 1),
+                prepare_ms=timing.prepare_ms / max(timing.prepare_launches, 1),
+                launches=timing.king_launches, recs=recs, bits=bits, cohort=cohort,
+                clock_mhz=clock)
 
 
 def main():
@@ -167,8 +356,8 @@ def main():
     import torch.distributed as dist
     import cuking_amd
     from cuking_amd.dist import (GpuStagedOps, PipelinedGather, all_pairs_king,
-                                 all_pairs_king_staged, rank_tile_share,
-                                 tile_partition)
+                                 all_pairs_king_staged, gather_results_device,
+                                 rank_tile_share, tile_partition)
     from cuking_amd.synth import cohort_to_device, plan_cohort
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -196,12 +385,21 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device(dev))
 
-    n = args.samples or int(round(10000 * math.sqrt(world)))
-    m = args.sites
-    thr = args.kin_threshold
-    wps = cuking_amd.words_per_sample(m)
-    sm = cuking_amd.Submatrix(n)
-    pairs = sm.NumPairs()
+    config = args.config or ("c3" if use_dist else "c1")
+    if config == "weak":
+        n, m, thr = int(round(10000 * math.sqrt(world))), 100_000, 0.05
+        workload_name = (f"weak scaling series: {n} samples x {m} sites "
+                         f"(10000 sqrt(N) samples), kin-threshold {thr}")
+        scaling = "weak"
+    else:
+        c = CONFIGS[config]
+        n, m, thr, workload_name = c["samples"], c["sites"], c["thr"], c["name"]
+        scaling = "strong" if use_dist else "weak"
+    n = args.samples or n
+    m = args.sites or m
+    thr = args.kin_threshold if args.kin_threshold is not None else thr
+    if args.samples or args.sites or args.kin_threshold is not None:
+        workload_name = f"custom: {n} samples x {m} sites, kin-threshold {thr}"
 
     ctx = cuking_amd.KingContext(local_rank)
     ctx.set_kernel(args.kernel)
@@ -212,9 +410,79 @@ def main():
     if args.counts_mode >= 0:
         ctx.set_option("counts_mode", args.counts_mode)
     ctx.timing_enable(True)
+    dtype_of = lambda roof: ("fp4 products, f32 accumulate (exact integers)"
+                             if roof["bound"] == "mfma" else "u32")
 
-    # Synthetic cohort, generated on the device (rank 0 owns the "packed
-    # input"; the other ranks receive it by broadcast inside every step).
+    # ------------------------------------------------------------------ N = 1
+    if not use_dist:
+        r = single_gpu_workload(args, ctx, n, m, thr, args.steps, args.warmup, local_rank)
+        roofline = roofline_block(
+            args, ctx, launch_pairs=r["pairs"], sites=m, wps=r["wps"], thr=thr,
+            king_ms=r["king_ms"], prepare_ms=r["prepare_ms"], launches=r["launches"],
+            workload_key=f"{n}x{m}", clock_mhz=r["clock_mhz"])
+        out = {
+            "metric": "sample-pairs/s (all-pairs KING)",
+            "value": r["pairs"] * args.steps / r["elapsed"],
+            "unit": "sample-pairs/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": r["elapsed"] / args.steps * 1e3,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": dtype_of(roofline), "data": "synthetic",
+            "config": {"workload": workload_name, "samples": n, "sites": m,
+                       "pairs": r["pairs"], "kin_threshold": thr,
+                       "results_per_step": int(len(r["recs"])), "kernel": args.kernel,
+                       "parallelism": "pair-space tiles over 1 GPU"},
+            "roofline": roofline,
+        }
+        if args.cpu_seconds > 0:
+            bits = r["bits"]
+
+            def host_bits(s):
+                return np.ascontiguousarray(bits[:s].cpu().numpy().view(np.uint64))
+            out["cpu_baseline"] = cpu_baseline(host_bits, r["wps"], r["recs"], thr,
+                                               args.cpu_seconds, n, args.cpu_threads)
+        else:
+            out["cpu_baseline"] = None
+        del r
+        torch.cuda.empty_cache()
+
+        extras = args.extra_configs
+        if extras is None:
+            extras = "c2,c3" if config == "c1" and not (args.samples or args.sites) else "none"
+        others = {}
+        for key in [k for k in extras.split(",") if k and k != "none"]:
+            c = CONFIGS[key]
+            # one untimed pass for the small one; the 9 s pass of c3 is its own warm-up
+            w, k = (1, 2) if c["samples"] <= 100_000 else (0, 1)
+            e = single_gpu_workload(args, ctx, c["samples"], c["sites"], c["thr"], k, w,
+                                    local_rank)
+            roof = roofline_block(
+                args, ctx, launch_pairs=e["pairs"], sites=c["sites"], wps=e["wps"],
+                thr=c["thr"], king_ms=e["king_ms"], prepare_ms=e["prepare_ms"],
+                launches=e["launches"], workload_key=f"{c['samples']}x{c['sites']}",
+                clock_mhz=e["clock_mhz"])
+            others[key] = {
+                "workload": c["name"] + ", on ONE GPU", "value": e["pairs"] * k / e["elapsed"],
+                "unit": "sample-pairs/s", "steps": k, "warmup": w,
+                "ms_per_step": e["elapsed"] / k * 1e3, "pairs": e["pairs"],
+                "results_per_step": int(len(e["recs"])),
+                "bitset_GB": e["bits"].numel() * 8 / 1e9,
+                "checks": "planted relatives all reported",
+                "roofline": {kk: roof[kk] for kk in
+                             ("bound", "achieved", "peak", "unit", "frac", "kernel_ms",
+                              "prepare_ms", "sustained_clock_mhz", "form")
+                             if kk in roof},
+            }
+            del e
+            torch.cuda.empty_cache()
+        if others:
+            out["other_configs"] = others
+        print(json.dumps(out), flush=True)
+        return
+
+    # ------------------------------------------------------------------ N > 1
+    wps = cuking_amd.words_per_sample(m)
+    sm = cuking_amd.Submatrix(n)
+    pairs = sm.NumPairs()
     cohort = plan_cohort(n, args.seed)
     kind, pa, pb = cohort_to_device(cohort, local_rank)
     bits = torch.zeros((n, wps), dtype=torch.int64, device=dev)
@@ -224,12 +492,15 @@ def main():
 
     results = torch.zeros((args.max_results, 6), dtype=torch.int32, device=dev)
     index_flag = torch.zeros(2, dtype=torch.int32, device=dev)
-    # second record buffer: with nccl the gather of one pass overlaps the
-    # kernel of the next (cuking_amd.dist.PipelinedGather)
-    results_b = torch.zeros_like(results) if use_dist else None
-    index_flag_b = torch.zeros_like(index_flag) if use_dist else None
+    # second record buffer: the gather of one pass overlaps the kernel of the
+    # next (cuking_amd.dist.PipelinedGather)
+    results_b = torch.zeros_like(results)
+    index_flag_b = torch.zeros_like(index_flag)
     num_tiles = ctx.num_tiles(sm) if args.kernel == "tiled" else 0
-    my_tiles = tile_partition(num_tiles, world)[rank] if use_dist else None
+    my_tiles = tile_partition(num_tiles, world)[rank]
+    # nccl gathers straight from the kernel's own counters; gloo (one-GPU
+    # rehearsals) needs host tensors and takes the staging path
+    device_gather = dist.get_backend() == "nccl"
 
     def compute_tiles(bit_sets, begin, end):
         index_flag.zero_()
@@ -240,18 +511,12 @@ def main():
         count, ovf = index_flag.tolist()   # waits for the kernel
         return results, count, ovf
 
-    # nccl gathers straight from the kernel's own counters; gloo (one-GPU
-    # rehearsals) needs host tensors and takes the staging path
-    device_gather = use_dist and dist.get_backend() == "nccl"
     gathered = [None]
-    staged = use_dist and args.dist_mode == "staged" and args.kernel == "tiled"
     tile = ctx.tile_samples()
     staged_ops = (GpuStagedOps(ctx, sm, wps, bits, thr, args.max_results,
                                num_streams=args.streams)
-                  if staged else None)
-
-    pipelined = (use_dist and device_gather and args.dist_mode == "resident" and
-                 args.kernel == "tiled" and
+                  if args.kernel == "tiled" else None)
+    pipelined = (device_gather and args.dist_mode == "resident" and args.kernel == "tiled" and
                  os.environ.get("CUKING_BENCH_NO_PIPELINE") != "1")
     pipe = PipelinedGather() if pipelined else None
     pending = [None]
@@ -263,9 +528,13 @@ def main():
         buf, flag = ((results, index_flag), (results_b, index_flag_b))[parity[0]]
         parity[0] ^= 1
         flag.zero_()
-        ctx.compute_king(sm, wps, bits, thr, args.max_results, buf, flag[0:1], flag[1:2],
-                         tile_range=my_tiles)
-        handle = pipe.begin(buf, flag)
+        error = None
+        try:
+            ctx.compute_king(sm, wps, bits, thr, args.max_results, buf, flag[0:1], flag[1:2],
+                             tile_range=my_tiles)
+        except Exception as e:  # noqa: BLE001 - raised on every rank by finish()
+            error = e
+        handle = pipe.begin(buf, flag, error=error)
         if pending[0] is not None:
             gathered[0] = pipe.finish(pending[0])
         pending[0] = handle
@@ -275,23 +544,19 @@ def main():
             gathered[0] = pipe.finish(pending[0])
             pending[0] = None
 
-    def step():
-        if pipelined:
+    def step(mode=None):
+        mode = mode or args.dist_mode
+        if pipelined and mode == "resident":
             return pipelined_step()
-        if not use_dist:
-            index_flag.zero_()
-            ctx.compute_king(sm, wps, bits, thr, args.max_results, results,
-                             index_flag[0:1], index_flag[1:2])
-        elif staged:
+        if mode == "staged" and staged_ops is not None:
             gathered[0], _ = all_pairs_king_staged(staged_ops, n, tile, bits,
                                                    num_chunks=args.chunks)
         else:
             gathered[0], _ = all_pairs_king(compute_tiles, num_tiles, bits,
-                                            broadcast=args.dist_mode != "resident")
+                                            broadcast=mode != "resident")
 
     def barrier():
-        if use_dist:
-            dist.barrier()
+        dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -307,130 +572,102 @@ def main():
         drain()          # the last pass's records are on rank 0 before the clock stops
     barrier()
     elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
-
+    host_or_dev = "cpu" if rehearsal else dev
+    t = torch.tensor([elapsed], dtype=torch.float64, device=host_or_dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t)
     timing = ctx.timing_collect()
-    # Records of the last step (rank 0): sanity + parity material.
-    if not use_dist:
-        count, ovf = index_flag.tolist()
-        if ovf:
-            raise SystemExit("result overflow: raise --max-results")
-        recs = results[:count].cpu().numpy().view(np.uint32).reshape(-1).view(
-            cuking_amd.KING_RESULT_DTYPE).copy()
-        recs = cuking_amd.sort_results(recs)
+    recs = gathered[0]
+
+    # every rank's pair-kernel time per step (HIP events on its own stream)
+    mine = torch.tensor([timing.king_ms / max(args.steps, 1),
+                         timing.prepare_ms / max(args.steps, 1)],
+                        dtype=torch.float64, device=host_or_dev)
+    per_rank = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(per_rank, mine)
+    rank_kernel_ms = [float(x[0]) for x in per_rank]
+    rank_prepare_ms = [float(x[1]) for x in per_rank]
+
+    # the gather alone: one unpipelined pass, timed from "my kernel is done"
+    barrier()
+    out_tiles = compute_tiles(bits, *my_tiles)
+    torch.cuda.synchronize()
+    dist.barrier()
+    g0 = time.perf_counter()
+    if device_gather:
+        gather_results_device(out_tiles[0], out_tiles[1])
     else:
-        recs = gathered[0]
+        from cuking_amd.dist import gather_results
+        gather_results(*out_tiles)
+    gather_ms = (time.perf_counter() - g0) * 1e3
+
+    # broadcast-inclusive passes: only rank 0 holds the bitset; the others
+    # start from zeros and receive it through RCCL inside the measured time
+    with_broadcast = None
+    if not args.no_broadcast_pass and args.dist_mode == "resident" and staged_ops is not None:
+        with_broadcast = {}
+        for mode in ("staged", "simple"):
+            if rank != 0:
+                bits.zero_()
+            barrier()
+            b0 = time.perf_counter()
+            step(mode)
+            barrier()
+            tb = torch.tensor([time.perf_counter() - b0], dtype=torch.float64,
+                              device=host_or_dev)
+            dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+            ok = gathered[0] is None or gathered[0].tobytes() == recs.tobytes()
+            if rank == 0 and not ok:
+                raise SystemExit(f"{mode} broadcast pass: records differ from the resident pass")
+            with_broadcast[mode] = {
+                "seconds": float(tb), "value": pairs / float(tb), "unit": "sample-pairs/s",
+                "bitset_bytes_broadcast": int(bits.numel() * 8),
+                "what": ("chunked RCCL broadcast from rank 0 overlapped with rectangle "
+                         "kernels (all_pairs_king_staged)" if mode == "staged" else
+                         "RCCL broadcast from rank 0, then equal tile ranges "
+                         "(all_pairs_king)") + "; one pass, records identical to the "
+                                               "resident pass"}
 
     out = None
     if rank == 0:
-        got = {(int(r["sample_i"]), int(r["sample_j"])) for r in recs}
-        missing = [p for p in cohort.planted
-                   if (min(p[0], p[1]), max(p[0], p[1])) not in got]
-        if missing and not args.no_check:
-            raise SystemExit(f"{len(missing)} planted relatives not reported")
-
-        ms_per_step = elapsed / args.steps * 1e3
-        value = pairs * args.steps / elapsed
-        bpp = cuking_amd.bytes_per_pair(wps)
-        # Dominant kernel = the pair kernel; rank 0's launches cover its own
-        # share of the pairs.
-        if not use_dist:
-            launch_pairs, launches = pairs, timing.king_launches
+        check_planted(recs, cohort, thr, args.no_check)
+        if args.dist_mode == "staged":
+            share = rank_tile_share((n + tile - 1) // tile, world, 0)
         else:
-            # rank 0's share of the pairs per step; its kernel time per step is
-            # the sum over its launches (rectangles on two streams may overlap,
-            # so this is an upper bound on the time the pair kernel was busy)
-            if staged:
-                share = rank_tile_share((n + tile - 1) // tile, world, 0)
-            else:
-                share = (my_tiles[1] - my_tiles[0]) / max(num_tiles, 1)
-            launch_pairs, launches = pairs * share, args.steps
-        king_ms = timing.king_ms / max(launches, 1)
-        achieved = launch_pairs * bpp / (king_ms * 1e-3) / 1e9 if king_ms > 0 else 0.0
-        workload = f"{n} samples x {m} sites, kin-threshold {thr}"
-        key = f"{n}x{m}"
-        kernel_name = ("king_stream_kernel" if args.kernel == "stream" else
-                       "king_mfma_kernel" if ctx.get_option("variant") == MFMA_VARIANT else
-                       "king_tiled_kernel")
-        variant = ctx.get_option("variant")
-        form = ("full" if args.counts_mode == 1 else "lean" if args.counts_mode == 0 else
-                "lean" if thr > 0 and thr * thr * 32 * wps >= (
-                    1.9 ** 2 if args.kernel == "tiled" and variant == MFMA_VARIANT else 1.6 ** 2)
-                else "full")
-        hbm_view = {
-            "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "algorithmic_bytes_per_pair": bpp,
-            "note": "algorithmic bytes (2 samples x words_per_sample x 8 B per pair, "
-                    "SURVEY.md 8d) / measured kernel time; operands are re-used from LDS and "
-                    "registers, so this exceeds 1.0 of HBM peak by design",
-        }
-        common = {
-            "traffic": load_traffic(key, kernel_name) if not use_dist else None,
-            "kernel": kernel_name, "kernel_ms": king_ms, "launches": timing.king_launches,
-            "prepare_ms": timing.prepare_ms / max(timing.prepare_launches, 1),
-        }
-        if args.kernel == "tiled" and variant == MFMA_VARIANT:
-            # Matrix-core kernel: algorithmic FLOP = pairs x sites x plane
-            # products x 2, against the dense FP4 MFMA peak.
-            macs = MFMA_MACS_PER_PAIR_SITE[form]
-            tflops = (launch_pairs * m * macs * 2 / (king_ms * 1e-3) / 1e12) if king_ms > 0 else 0.0
-            roofline = {
-                "bound": "mfma", "achieved": tflops, "peak": MFMA_FP4_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": tflops / MFMA_FP4_PEAK_TFLOPS, **common,
-                "form": form, "macs_per_pair_site": macs,
-                "note": "fp4 (E2M1) v_mfma_f32_32x32x64_f8f6f4, exact integer sums in f32; "
-                        "algorithmic FLOP = pairs x sites x plane products x 2 (padding of "
-                        "tiles and of the last k-step not counted); the chip holds ~2.1 GHz "
-                        "under this load, where MFMAs alone reach ~9.3 PF "
-                        "(profiles/r01_mfma_microbench.txt)",
-                "hbm": hbm_view,
-            }
-        else:
-            roofline = {"bound": "hbm", **hbm_view, **common}
-            # VALU view: wave64 issue cycles one SIMD spends per pair and 32-site
-            # word (at the nominal clock) against the measured floor for this mix.
-            cyc = (king_ms * 1e-3 * NOMINAL_CLOCK_HZ * NUM_SIMDS * 64 /
-                   (launch_pairs * wps)) if king_ms > 0 else 0.0
-            floor = VALU_FLOOR_CYCLES_PER_PAIR_WORD[form]
-            roofline["valu"] = {
-                "form": form,
-                "ops_per_pair_word": VALU_OPS_PER_PAIR_WORD[form],
-                "achieved_cycles_per_pair_word": cyc,
-                "floor_cycles_per_pair_word": floor,
-                "frac": floor / cyc if cyc else 0.0,
-            }
-        # the arithmetic the sums are computed in
-        dtype = ("fp4 products, f32 accumulate (exact integers)"
-                 if roofline["bound"] == "mfma" else "u32")
+            share = (my_tiles[1] - my_tiles[0]) / max(num_tiles, 1)
+        king_ms = timing.king_ms / max(args.steps, 1)
+        roofline = roofline_block(
+            args, ctx, launch_pairs=pairs * share, sites=m, wps=wps, thr=thr, king_ms=king_ms,
+            prepare_ms=timing.prepare_ms / max(timing.prepare_launches, 1),
+            launches=timing.king_launches, workload_key=f"{n}x{m}", clock_mhz=None,
+            use_profile=False)
+        roofline["note_rank"] = ("rank 0's launches over its share of the pairs "
+                                 f"({share:.4f}); per-rank figures under config")
         out = {
-            "metric": "sample-pairs/s (all-pairs KING)", "value": value,
+            "metric": "sample-pairs/s (all-pairs KING)", "value": pairs * args.steps / elapsed,
             "unit": "sample-pairs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": dtype, "data": "synthetic",
-            "config": {"workload": workload, "samples": n, "sites": m,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": dtype_of(roofline), "data": "synthetic",
+            "config": {"workload": workload_name, "samples": n, "sites": m,
                        "pairs": pairs, "kin_threshold": thr,
-                       "results_per_step": int(len(recs)),
-                       "kernel": args.kernel,
-                       "parallelism": f"pair-space tiles over {world} GPU(s)"
-                                      + ((", bitset resident on every GPU, records gathered"
+                       "results_per_step": int(len(recs)), "kernel": args.kernel,
+                       "parallelism": (f"pair-space tiles over {world} GPU(s), "
+                                       + ("bitset resident on every GPU, records gathered on "
+                                          "rank 0 (gather pipelined behind the next pass)"
                                           if args.dist_mode == "resident" else
-                                          f", {args.dist_mode} bitset broadcast") if use_dist else "")},
+                                          f"{args.dist_mode} bitset broadcast inside every step")),
+                       "rccl_ranks": world, "backend": dist.get_backend(),
+                       "rank_kernel_ms_per_step": rank_kernel_ms,
+                       "rank_prepare_ms_per_step": rank_prepare_ms,
+                       "gather_ms_unpipelined": gather_ms,
+                       "bitset_bytes_per_rank": int(bits.numel() * 8)},
+            "with_broadcast": with_broadcast,
             "roofline": roofline,
+            "cpu_baseline": None,
         }
-        if not use_dist and args.cpu_seconds > 0:
-            def host_bits(s):
-                return np.ascontiguousarray(bits[:s].cpu().numpy().view(np.uint64))
-            out["cpu_baseline"] = cpu_baseline(host_bits, wps, recs, thr, args.cpu_seconds,
-                                               n, args.cpu_threads)
-        else:
-            out["cpu_baseline"] = None
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    dist.barrier()
+    dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out), flush=True)
 

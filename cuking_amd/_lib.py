@@ -94,6 +94,7 @@ SIGNATURES = {
     "cuking_timing_collect": (_int, [_vp, C.POINTER(C.c_double),
                                      C.POINTER(_u64), C.POINTER(C.c_double),
                                      C.POINTER(_u64)]),
+    "cuking_clock_probe": (_int, [_vp, _u64, _vp, _vp]),
     "cuking_synth_bitset": (_int, [_vp, _u64, _vp, _vp, _vp, _u32, _u32, _u32,
                                    _u32, _vp, _vp]),
 }

@@ -326,6 +326,21 @@ class KingContext:
             self.handle, C.byref(a), C.byref(na), C.byref(b), C.byref(nb)))
         return KernelTiming(a.value, na.value, b.value, nb.value)
 
+    def clock_probe(self, microseconds: int, stream):
+        """Starts the sustained-clock probe on ``stream`` (a side stream);
+        returns a function that waits for it and gives the clock in MHz."""
+        import torch
+        ticks = torch.zeros(2, dtype=torch.int64, device=f"cuda:{self.device}")
+        stream.wait_stream(torch.cuda.current_stream())
+        check(self.lib.cuking_clock_probe(self.handle, int(microseconds), ticks.data_ptr(),
+                                          _stream_handle(stream)))
+
+        def result() -> float:
+            stream.synchronize()
+            shader, real = ticks.tolist()
+            return 100.0 * shader / real if real else 0.0
+        return result
+
     # -- helpers --------------------------------------------------------------
     def _check_bits(self, sm: Submatrix, wps: int, bit_sets) -> None:
         import torch

@@ -1139,6 +1139,17 @@ cuking_status cuking_timing_collect(cuking_ctx *ctx, double *king_ms,
   return CUKING_OK;
 }
 
+cuking_status cuking_clock_probe(cuking_ctx *ctx, uint64_t microseconds,
+                                 uint64_t *d_ticks, void *stream) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  if (d_ticks == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null out pointer");
+  if (microseconds == 0 || microseconds > 60ull * 1000 * 1000)
+    return fail(CUKING_ERR_INVALID_ARGUMENT, "probe time outside (0, 60 s]");
+  HIP_TRY(launch_clock_probe(microseconds, d_ticks, (hipStream_t)stream));
+  return CUKING_OK;
+}
+
 // ---- synthetic inputs -----------------------------------------------------
 
 cuking_status cuking_synth_bitset(cuking_ctx *ctx, uint64_t seed,

@@ -206,6 +206,9 @@ hipError_t launch_synth(uint64_t seed, const uint32_t *d_kind,
                         uint32_t num_sites, uint32_t words_per_sample,
                         uint64_t *d_bit_set, hipStream_t stream);
 
+hipError_t launch_clock_probe(uint64_t microseconds, uint64_t *d_out,
+                              hipStream_t stream);
+
 // Submatrix helpers usable on both sides (cuking.cu:154-175).
 __host__ __device__ inline uint32_t sm_num_rows(const cuking_submatrix &s) {
   return s.i_end - s.i_begin;

@@ -101,7 +101,36 @@ __global__ __launch_bounds__(256) void synth_kernel(
   dst[plane + w] = hom_word;
 }
 
+// One wavefront that watches the two clocks of its compute unit for a fixed
+// wall time: s_memtime ticks with the shader clock, s_memrealtime at a constant
+// 100 MHz, so delta / delta x 100 MHz is the clock the chip sustains while
+// whatever else is running (MI355X_MICROARCH.md, "DVFS give-back" item 6).  It
+// sleeps between looks and leaves after `ticks_100mhz` of real time whatever
+// happens.  out = {shader ticks, real ticks}.
+__global__ __launch_bounds__(64) void clock_probe_kernel(uint64_t ticks_100mhz,
+                                                         uint64_t *out) {
+  const uint64_t r0 = __builtin_amdgcn_s_memrealtime();
+  const uint64_t c0 = __builtin_amdgcn_s_memtime();
+  uint64_t r1 = r0;
+  while (r1 - r0 < ticks_100mhz) {
+    __builtin_amdgcn_s_sleep(127);
+    r1 = __builtin_amdgcn_s_memrealtime();
+  }
+  const uint64_t c1 = __builtin_amdgcn_s_memtime();
+  r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) {
+    out[0] = c1 - c0;
+    out[1] = r1 - r0;
+  }
+}
+
 }  // namespace
+
+hipError_t launch_clock_probe(uint64_t microseconds, uint64_t *d_out,
+                              hipStream_t stream) {
+  clock_probe_kernel<<<dim3(1), dim3(64), 0, stream>>>(microseconds * 100, d_out);
+  return hipGetLastError();
+}
 
 hipError_t launch_synth(uint64_t seed, const uint32_t *d_kind,
                         const uint32_t *d_pa, const uint32_t *d_pb,

@@ -279,6 +279,15 @@ cuking_status cuking_timing_collect(cuking_ctx *ctx, double *king_ms,
                                     uint64_t *king_launches, double *prepare_ms,
                                     uint64_t *prepare_launches);
 
+/* Sustained shader clock while other work runs: enqueues ONE wavefront on
+ * `stream` (use a stream of its own) that watches the shader-clock counter and
+ * the constant 100 MHz counter for `microseconds` of wall time and then writes
+ * d_ticks[0] = shader ticks, d_ticks[1] = 100 MHz ticks; clock in MHz =
+ * 100 * d_ticks[0] / d_ticks[1].  It holds one wave slot of one CU meanwhile,
+ * so it belongs in a pass of its own, not in a timed region. */
+cuking_status cuking_clock_probe(cuking_ctx *ctx, uint64_t microseconds,
+                                 uint64_t *d_ticks, void *stream);
+
 /* ------------------------------------------------------------------------ */
 /* Synthetic inputs for benchmarks (no reference counterpart).    */
 /* ------------------------------------------------------------------------ */

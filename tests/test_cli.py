@@ -333,6 +333,48 @@ def test_device_pack_multichunk_tables(c0, oracle):
 
 
 @pytest.mark.gpu
+def test_device_pack_large_bitset_tiny_files(tmp_path, oracle):
+    """--pack=device with a 6 GB bitset and sixteen tiny part files: the all-ones
+    fill of the bitset (milliseconds at this size, on the null stream) must be
+    complete before the first pack kernel clears bits on a reader thread's own
+    non-blocking stream -- otherwise the fill overwrites them and those
+    genotypes silently turn missing."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    n, m, m_used, thr = 60_000, 400_000, 20_000, 0.05
+    who = np.array(sorted({0, 1, 2, 3, 777, 778, 20_000, 20_001, 31_415, 31_416, 44_444,
+                           44_445, 59_000, 59_001, 59_996, 59_997, 59_998, 59_999,
+                           128, 129, 255, 256, 10_000, 10_001}))
+    rng = np.random.default_rng(11)
+    sub = random_genotypes(rng, len(who), m_used, missing=0.02)
+    sub[1], sub[5], sub[-1] = sub[0], sub[4], sub[-2]          # duplicates
+    d = tmp_path / "in"
+    d.mkdir()
+    ids = [f"S{k:06d}" for k in range(n)]
+    (d / "metadata.json").write_text(json.dumps({"num_sites": m, "samples": ids}))
+    bounds = np.linspace(0, m_used, 17).astype(int)
+    for f in range(16):
+        block = sub[:, bounds[f]:bounds[f + 1]].T
+        row, col = np.nonzero(block >= 0)
+        t = pa.table({"row_idx": (row + bounds[f]).astype(np.int64),
+                      "col_idx": who[col].astype(np.int64),
+                      "n_alt_alleles": block[row, col].astype(np.int32)})
+        pq.write_table(t, d / f"part-{f:05d}.parquet", compression="zstd")
+    out = tmp_path / "out"
+    for attempt in range(2):
+        p = run_cli("--input_uri", d, "--output_uri", out, f"--kin_threshold={thr}",
+                    "--pack=device", "--num_reader_threads=16", check=True)
+        full = np.full((len(who), m), -1, dtype=np.int8)
+        full[:, :m_used] = sub
+        exp, ovf, _ = oracle.compute(oracle.submatrix(len(who)),
+                                     oracle.bitset_from_genotypes(full), thr)
+        assert ovf == 0 and len(exp) >= 3
+        exp = exp.copy()
+        exp["sample_i"], exp["sample_j"] = who[exp["sample_i"]], who[exp["sample_j"]]
+        check_output(out / "part-00000.snappy.parquet", exp, ids)
+
+
+@pytest.mark.gpu
 def test_c0_split_factor_shards(c0, oracle):
     """README.md:94-102: k = 3 => 6 shards, each its own part file."""
     out = c0["dir"] / "out_split"

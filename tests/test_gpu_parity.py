@@ -709,3 +709,89 @@ def test_c1_sample_order_symmetry(ctx, c1):
     mirrored["sample_j"] = n - 1 - rev["sample_i"]
     mirrored = cuking_amd.sort_results(np.ascontiguousarray(mirrored))
     assert mirrored.tobytes() == res.tobytes()
+
+
+def test_rect_needs_prepared_samples(ctx, oracle):
+    """cuking_compute_king_rect only reads what cuking_prepare_samples has
+    converted for THIS block: unprepared samples, or a workspace that another
+    call has converted for a different block since, are FAILED_PRECONDITION,
+    not silently wrong sums."""
+    import torch
+    for variant in (0, 5):
+        select(ctx, "tiled", variant)
+        tile = ctx.tile_samples()
+        n = 5 * tile - 17
+        geno = random_genotypes(np.random.default_rng(77), n, 260, missing=0.03)
+        geno[n - 1] = geno[0]
+        bits = oracle.bitset_from_genotypes(geno)
+        d_bits = ctx.upload_bitset(bits)
+        wps = bits.shape[1]
+        sm = cuking_amd.Submatrix(n)
+        res = torch.zeros((200000, 6), dtype=torch.int32, device="cuda:0")
+        idx = torch.zeros(2, dtype=torch.int32, device="cuda:0")
+        other = ctx.upload_bitset(bits[:tile].copy())
+        ctx.run(cuking_amd.Submatrix(tile), wps, other, 0.4)     # workspace: another block
+        with pytest.raises(cuking_amd.CukingError, match="prepare"):
+            ctx.compute_king_rect(sm, wps, d_bits, (0, tile), (0, tile), 0.0, 200000, res,
+                                  idx[0:1], idx[1:2])
+        ctx.prepare_samples(sm, wps, d_bits, 0, 2 * tile)
+        with pytest.raises(cuking_amd.CukingError, match="column samples"):
+            ctx.compute_king_rect(sm, wps, d_bits, (0, tile), (tile, 3 * tile), 0.0, 200000,
+                                  res, idx[0:1], idx[1:2])
+        with pytest.raises(cuking_amd.CukingError, match="row samples"):
+            ctx.compute_king_rect(sm, wps, d_bits, (0, 4 * tile, 3 * tile), (0, 2 * tile), 0.0,
+                                  200000, res, idx[0:1], idx[1:2])
+        ctx.compute_king_rect(sm, wps, d_bits, (0, 2 * tile), (0, 2 * tile), 0.0, 200000, res,
+                              idx[0:1], idx[1:2])                # prepared: fine
+        ctx.run(cuking_amd.Submatrix(tile), wps, other, 0.4)     # converts another block
+        with pytest.raises(cuking_amd.CukingError, match="prepare"):
+            ctx.compute_king_rect(sm, wps, d_bits, (0, tile), (0, tile), 0.0, 200000, res,
+                                  idx[0:1], idx[1:2])
+        # a whole-block call converts everything: rectangles may follow it
+        whole = ctx.run(sm, wps, d_bits, -0.05)
+        idx.zero_()
+        ctx.compute_king_rect(sm, wps, d_bits, (0, n), (0, n), -0.05, 200000, res,
+                              idx[0:1], idx[1:2])
+        torch.cuda.synchronize()
+        cnt, ovf = idx.tolist()
+        got = cuking_amd.sort_results(res[:cnt].cpu().numpy().view(np.uint32).reshape(-1).view(
+            cuking_amd.KING_RESULT_DTYPE).copy())
+        exp, _, _ = oracle.compute(oracle.submatrix(n), bits, -0.05)
+        assert ovf == 0 and got.tobytes() == whole.tobytes() == exp.tobytes()
+
+
+@pytest.mark.parametrize("variant", [0, 5])
+def test_calls_on_two_streams_of_one_context(ctx, oracle, variant):
+    """Two blocks back to back on two non-blocking streams of ONE context: the
+    second call's layout conversion overwrites the workspace the first call's
+    pair kernel reads, so the library has to order them (event wait)."""
+    import torch
+    select(ctx, "tiled", variant)
+    rng = np.random.default_rng(5)
+    n1, n2, m = 2300, 900, 6000
+    g1 = random_genotypes(rng, n1, m, missing=0.02)
+    g2 = random_genotypes(rng, n2, m, missing=0.02)
+    g1[n1 - 1], g2[n2 - 1] = g1[3], g2[5]
+    b1, b2 = oracle.bitset_from_genotypes(g1), oracle.bitset_from_genotypes(g2)
+    d1, d2 = ctx.upload_bitset(b1), ctx.upload_bitset(b2)
+    thr = 0.03
+    e1, _, _ = oracle.compute(oracle.submatrix(n1), b1, thr, threads=16)
+    e2, _, _ = oracle.compute(oracle.submatrix(n2), b2, thr, threads=16)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    bufs = [(torch.zeros((1 << 16, 6), dtype=torch.int32, device="cuda:0"),
+             torch.zeros(2, dtype=torch.int32, device="cuda:0")) for _ in range(2)]
+    torch.cuda.synchronize()
+    for rounds in range(3):
+        for (res, idx) in bufs:
+            idx.zero_()
+        torch.cuda.synchronize()
+        ctx.compute_king(cuking_amd.Submatrix(n1), b1.shape[1], d1, thr, 1 << 16, bufs[0][0],
+                         bufs[0][1][0:1], bufs[0][1][1:2], stream=s1)
+        ctx.compute_king(cuking_amd.Submatrix(n2), b2.shape[1], d2, thr, 1 << 16, bufs[1][0],
+                         bufs[1][1][0:1], bufs[1][1][1:2], stream=s2)
+        torch.cuda.synchronize()
+        for (res, idx), exp in zip(bufs, (e1, e2)):
+            cnt, ovf = idx.tolist()
+            got = cuking_amd.sort_results(res[:cnt].cpu().numpy().view(np.uint32).reshape(
+                -1).view(cuking_amd.KING_RESULT_DTYPE).copy())
+            assert ovf == 0 and got.tobytes() == exp.tobytes(), rounds
