@@ -358,34 +358,9 @@ cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->planes), need));
     ctx->planes_bytes = need;
   }
-  const uint32_t nb = tiles.num_bands();
-  if ((size_t)nb + 1 > ctx->band_prefix_entries) {
-    HIP_TRY(hipDeviceSynchronize());
-    if (ctx->band_prefix) HIP_TRY(hipFree(ctx->band_prefix));
-    ctx->band_prefix = nullptr;
-    ctx->band_prefix_entries = 0;
-    ctx->prefix_for = TileSpace{0, 0, 0, 0};
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->band_prefix),
-                      ((size_t)nb + 1) * sizeof(uint64_t)));
-    ctx->band_prefix_entries = (size_t)nb + 1;
-  }
-  const TileSpace &pf = ctx->prefix_for;
-  if (pf.tiles_r != tiles.tiles_r || pf.tiles_c != tiles.tiles_c ||
-      pf.band_rows != tiles.band_rows || pf.diag != tiles.diag) {
-    std::vector<uint64_t> prefix((size_t)nb + 1, 0);
-    for (uint32_t b = 0; b < nb; ++b)
-      prefix[b + 1] = prefix[b] + tiles.band_tiles(b);
-    // Small and pageable: wait until the host buffer may go away.
-    HIP_TRY(hipMemcpyAsync(ctx->band_prefix, prefix.data(),
-                           prefix.size() * sizeof(uint64_t),
-                           hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    ctx->prefix_for = tiles;
-  }
-
-  if (need == 0) return CUKING_OK;
   // Book-keeping of what the workspace holds, and ordering against kernels on
-  // other streams that still read what is about to be overwritten.
+  // other streams that still read what is about to be overwritten -- the planes
+  // AND the band prefix below, so this comes before either is touched.
   const uint32_t all_tiles = (geo.s_stride + 63) / 64;
   const uint32_t t_end = s_tile_end < all_tiles ? s_tile_end : all_tiles;
   cuking_ctx::Prepared &pr = ctx->prepared;
@@ -394,9 +369,12 @@ cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
   // since have read (2); or of tiles whose readers were last ordered behind a
   // different stream (1).  Fresh tiles of the same block have no readers.
   const bool other_stream = pr.ordered_valid && pr.ordered_on != stream;
-  bool must_wait = false;
+  const TileSpace &pf = ctx->prefix_for;
+  const bool new_prefix = pf.tiles_r != tiles.tiles_r || pf.tiles_c != tiles.tiles_c ||
+                          pf.band_rows != tiles.band_rows || pf.diag != tiles.diag;
+  bool must_wait = new_prefix && !ctx->readers.empty();
   if (!same_block(pr, sm, words_per_sample, variant, d_bit_sets)) {
-    must_wait = !ctx->readers.empty();
+    must_wait = must_wait || !ctx->readers.empty();
     pr.valid = true;
     pr.sm = sm;
     pr.words_per_sample = words_per_sample;
@@ -411,6 +389,30 @@ cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
     if (st != CUKING_OK) return st;
   }
   for (uint32_t t = s_tile_begin; t < t_end; ++t) pr.tiles[t] = 1;
+  const uint32_t nb = tiles.num_bands();
+  if ((size_t)nb + 1 > ctx->band_prefix_entries) {
+    HIP_TRY(hipDeviceSynchronize());
+    if (ctx->band_prefix) HIP_TRY(hipFree(ctx->band_prefix));
+    ctx->band_prefix = nullptr;
+    ctx->band_prefix_entries = 0;
+    ctx->prefix_for = TileSpace{0, 0, 0, 0};
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->band_prefix),
+                      ((size_t)nb + 1) * sizeof(uint64_t)));
+    ctx->band_prefix_entries = (size_t)nb + 1;
+  }
+  if (new_prefix) {
+    std::vector<uint64_t> prefix((size_t)nb + 1, 0);
+    for (uint32_t b = 0; b < nb; ++b)
+      prefix[b + 1] = prefix[b] + tiles.band_tiles(b);
+    // Small and pageable: wait until the host buffer may go away.
+    HIP_TRY(hipMemcpyAsync(ctx->band_prefix, prefix.data(),
+                           prefix.size() * sizeof(uint64_t),
+                           hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    ctx->prefix_for = tiles;
+  }
+
+  if (need == 0) return CUKING_OK;
   EventPair *ev = nullptr;
   if (ctx->timing) HIP_TRY(ctx->prepare_timer.begin(stream, &ev));
   HIP_TRY(launch_prepare_planes(v.layout, d_bit_sets, words_per_sample, geo, ctx->planes,
