@@ -32,6 +32,13 @@ HIP_FLAGS = [
 ]
 
 
+# host/multi_gpu.cc: HIP runtime API (streams, events, copies) and RCCL from a
+# plain g++ translation unit -- no device code outside csrc/.
+ROCM = Path(os.environ.get("ROCM_PATH", "/opt/rocm"))
+ROCM_HOST_FLAGS = ["-D__HIP_PLATFORM_AMD__=1", f"-isystem{ROCM / 'include'}"]
+ROCM_HOST_LIBS = [f"-L{ROCM / 'lib'}", "-lrccl", "-lamdhip64"]
+
+
 def _hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -98,9 +105,9 @@ def build_cli(force: bool = False) -> Path:
     inc, libdir, libs = arrow_flags()
     CLI_PATH.parent.mkdir(exist_ok=True)
     cmd = ["g++", "-O2", "-std=c++20", "-Wall", "-pthread",
-           f"-I{INCLUDE}", f"-I{HOST}", f"-isystem{inc}",
+           f"-I{INCLUDE}", f"-I{HOST}", f"-isystem{inc}", *ROCM_HOST_FLAGS,
            *map(str, srcs), "-o", str(CLI_PATH),
-           f"-L{PKG}", "-l:libcuking_amd.so", f"-L{libdir}", *libs,
+           f"-L{PKG}", "-l:libcuking_amd.so", f"-L{libdir}", *libs, *ROCM_HOST_LIBS,
            f"-Wl,-rpath,{libdir}", "-Wl,-rpath,$ORIGIN/..",
            "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.run(cmd, check=True)

@@ -27,7 +27,9 @@
 #include "cuking_amd.h"
 #include "flags.h"
 #include "metadata.h"
+#include "multi_gpu.h"
 #include "parquet_io.h"
+#include "schedule.h"
 #include "thread_pool.h"
 
 namespace {
@@ -216,6 +218,45 @@ class DevicePacker {
   int next_ = 0;
 };
 
+// --print_schedule: what each rank of a --num_gpus run would do, as JSON (host
+// arithmetic only; the tests compare it with cuking_amd/dist.py and check by
+// brute force that every pair is covered exactly once).
+void PrintSchedule(const Flags &flags, const cuking_submatrix &sm) {
+  const uint32_t world = flags.num_gpus ? flags.num_gpus : 1;
+  const uint32_t tile = cuking_tile_samples(nullptr);
+  const uint64_t num_tiles = cuking_num_tiles(nullptr, &sm);
+  const uint32_t stored = cuking_submatrix_num_samples(&sm);
+  const bool diag = sm.i_begin == sm.j_begin;
+  const bool staged = diag && flags.kernel != "stream" && flags.multi_gpu_mode != "simple";
+  std::cout << "{\"world\": " << world << ", \"tile\": " << tile << ", \"num_tiles\": "
+            << num_tiles << ", \"stored_samples\": " << stored << ", \"mode\": \""
+            << (staged ? "staged" : "simple") << "\", \"tile_ranges\": [";
+  const auto parts = cuking_host::TilePartition(num_tiles, world);
+  for (uint32_t r = 0; r < world; ++r)
+    std::cout << (r ? ", " : "") << "[" << parts[r].begin << ", " << parts[r].end << "]";
+  std::cout << "], \"chunks\": [";
+  const auto chunks = cuking_host::ChunkRanges(stored, tile, flags.bcast_chunks);
+  for (size_t c = 0; c < chunks.size(); ++c)
+    std::cout << (c ? ", " : "") << "[" << chunks[c].begin << ", " << chunks[c].end << "]";
+  std::cout << "], \"staged\": [";
+  for (uint32_t r = 0; r < world; ++r) {
+    std::cout << (r ? ", " : "") << "[";
+    const auto steps = cuking_host::StagedSchedule(stored, tile, world, r, flags.bcast_chunks);
+    for (size_t k = 0; k < steps.size(); ++k) {
+      const auto &s = steps[k];
+      std::cout << (k ? ", " : "") << "{\"chunk\": [" << s.chunk.begin << ", " << s.chunk.end
+                << "], \"rows\": ";
+      if (s.has_rect)
+        std::cout << "[" << s.row_begin << ", " << s.row_end << ", " << s.row_step << "]";
+      else
+        std::cout << "null";
+      std::cout << "}";
+    }
+    std::cout << "]";
+  }
+  std::cout << "]}" << std::endl;
+}
+
 Status Run(const Flags &flags) {
   {
     const std::string err = cuking_host::ValidateFlags(flags);
@@ -243,6 +284,12 @@ Status Run(const Flags &flags) {
   RETURN_IF_ERROR(FromAbi(cuking_submatrix_init(&sm, num_samples, flags.split_factor,
                                                 flags.shard_index)));
 
+  if (flags.print_schedule) {  // host arithmetic only: no GPU, no input tables
+    PrintSchedule(flags, sm);
+    return Status::Ok();
+  }
+  const bool multi_gpu = flags.num_gpus > 0;
+
   const size_t bit_set_words =
       (size_t)words_per_sample * cuking_submatrix_num_samples(&sm);
   const size_t bit_set_bytes = bit_set_words * sizeof(uint64_t);
@@ -260,7 +307,9 @@ Status Run(const Flags &flags) {
     RETURN_IF_ERROR(FromAbi(cuking_ctx_set_kernel(
         buf.ctx,
         flags.kernel == "stream" ? CUKING_KERNEL_STREAM : CUKING_KERNEL_TILED)));
-    RETURN_IF_ERROR(FromAbi(cuking_device_alloc(buf.ctx, bit_set_bytes, &buf.d_bits)));
+    // (with --num_gpus and host pack every rank allocates its own copy later)
+    if (!multi_gpu || pack_on_device)
+      RETURN_IF_ERROR(FromAbi(cuking_device_alloc(buf.ctx, bit_set_bytes, &buf.d_bits)));
     if (pack_on_device) {
       RETURN_IF_ERROR(FromAbi(
           cuking_memset_async(buf.ctx, buf.d_bits, 0xFF, bit_set_bytes, nullptr)));
@@ -364,7 +413,7 @@ Status Run(const Flags &flags) {
       return FailedPrecondition("Invalid value for n_alt_alleles encountered");
     if (pack_status & 2u)
       return InvalidArgument("row_idx outside the padded sites encountered");
-  } else {
+  } else if (!multi_gpu) {
     RETURN_IF_ERROR(FromAbi(cuking_copy_to_device(buf.ctx, buf.d_bits, buf.host_bits,
                                                   bit_set_bytes, nullptr)));
     RETURN_IF_ERROR(FromAbi(cuking_stream_synchronize(buf.ctx, nullptr)));
@@ -373,47 +422,96 @@ Status Run(const Flags &flags) {
   }
   Done(&sw);
 
-  const uint32_t max_results = flags.max_results;
-  std::cout << "Allocating " << CeilMiB((uint64_t)max_results * sizeof(cuking_result))
-            << " MiB of memory for results..." << std::flush;
-  RETURN_IF_ERROR(FromAbi(cuking_device_alloc(
-      buf.ctx, (size_t)max_results * sizeof(cuking_result), &buf.d_results)));
-  RETURN_IF_ERROR(FromAbi(cuking_device_alloc(buf.ctx, 2 * sizeof(uint32_t), &buf.d_counters)));
-  RETURN_IF_ERROR(FromAbi(
-      cuking_memset_async(buf.ctx, buf.d_counters, 0, 2 * sizeof(uint32_t), nullptr)));
-  Done(&sw);
-
   const uint32_t num_rows = cuking_submatrix_num_rows(&sm);
   const uint32_t num_cols = cuking_submatrix_num_cols(&sm);
-  std::cout << "Running KING HIP kernel for " << num_rows << " x " << num_cols
-            << " matrix..." << std::flush;
-  uint32_t *d_counters = static_cast<uint32_t *>(buf.d_counters);
-  RETURN_IF_ERROR(FromAbi(cuking_compute_king(
-      buf.ctx, &sm, words_per_sample, static_cast<uint64_t *>(buf.d_bits),
-      flags.kin_threshold, max_results, static_cast<cuking_result *>(buf.d_results),
-      d_counters, d_counters + 1, nullptr)));
-  uint32_t counters[2] = {0, 0};
-  RETURN_IF_ERROR(FromAbi(cuking_copy_to_host(buf.ctx, counters, d_counters,
-                                              sizeof(counters), nullptr)));
-  RETURN_IF_ERROR(FromAbi(cuking_stream_synchronize(buf.ctx, nullptr)));  // errors surface here
-  const double kernel_seconds = sw.ElapsedAndReset();
-  std::cout << " (" << std::fixed << std::setprecision(3) << kernel_seconds << "s)"
-            << std::endl;
+  std::vector<cuking_result> results;
+  double kernel_seconds = 0;
+  std::ostringstream multi_summary;
+  if (multi_gpu) {
+    // The shard over flags.num_gpus GPUs: chunked RCCL broadcast of the packed
+    // bitset, pair-space shares per rank, records gathered on rank 0.
+    std::cout << "Running KING HIP kernel for " << num_rows << " x " << num_cols
+              << " matrix on " << flags.num_gpus << " GPU(s)..." << std::flush;
+    cuking_host::MultiGpuInput in;
+    in.num_gpus = (int)flags.num_gpus;
+    in.first_device = flags.device;
+    in.kernel = flags.kernel;
+    in.mode = flags.multi_gpu_mode;
+    in.chunks = flags.bcast_chunks;
+    in.sm = sm;
+    in.words_per_sample = words_per_sample;
+    in.host_bits = pack_on_device ? nullptr : static_cast<const uint64_t *>(buf.host_bits);
+    in.d_bits_rank0 = static_cast<uint64_t *>(buf.d_bits);
+    in.kin_threshold = flags.kin_threshold;
+    in.max_results = flags.max_results;
+    cuking_host::MultiGpuOutput mg;
+    std::string code;
+    const std::string err = cuking_host::RunMultiGpu(in, &mg, &code);
+    if (!err.empty()) return {code, err};
+    kernel_seconds = sw.ElapsedAndReset();
+    std::cout << " (" << std::fixed << std::setprecision(3) << kernel_seconds << "s)"
+              << std::endl;
+    results.swap(mg.results);
+    multi_summary << ", \"gpus\": " << flags.num_gpus << ", \"multi_gpu_mode\": \"" << mg.mode
+                  << "\", \"bytes_broadcast\": " << mg.bytes_broadcast
+                  << ", \"exchange_and_compute_seconds\": " << std::setprecision(6)
+                  << mg.exchange_and_compute_seconds << ", \"gather_seconds\": "
+                  << mg.gather_seconds << ", \"rank_kernel_ms\": [";
+    for (size_t r = 0; r < mg.rank_kernel_ms.size(); ++r)
+      multi_summary << (r ? ", " : "") << std::setprecision(3) << mg.rank_kernel_ms[r];
+    multi_summary << "], \"rank_results\": [";
+    for (size_t r = 0; r < mg.rank_results.size(); ++r)
+      multi_summary << (r ? ", " : "") << mg.rank_results[r];
+    multi_summary << "]";
+    if (buf.host_bits) {
+      cuking_host_free(buf.ctx, buf.host_bits);
+      buf.host_bits = nullptr;
+    }
+    std::cout << "Processing " << results.size() << " results..." << std::flush;
+  } else {
+    const uint32_t max_results = flags.max_results;
+    std::cout << "Allocating " << CeilMiB((uint64_t)max_results * sizeof(cuking_result))
+              << " MiB of memory for results..." << std::flush;
+    RETURN_IF_ERROR(FromAbi(cuking_device_alloc(
+        buf.ctx, (size_t)max_results * sizeof(cuking_result), &buf.d_results)));
+    RETURN_IF_ERROR(
+        FromAbi(cuking_device_alloc(buf.ctx, 2 * sizeof(uint32_t), &buf.d_counters)));
+    RETURN_IF_ERROR(FromAbi(
+        cuking_memset_async(buf.ctx, buf.d_counters, 0, 2 * sizeof(uint32_t), nullptr)));
+    Done(&sw);
 
-  if (counters[1] != 0)  // cuking.cu:747-751
-    return ResourceExhausted(
-        "Could not store all results: try increasing the --max_results parameter.");
+    std::cout << "Running KING HIP kernel for " << num_rows << " x " << num_cols
+              << " matrix..." << std::flush;
+    uint32_t *d_counters = static_cast<uint32_t *>(buf.d_counters);
+    RETURN_IF_ERROR(FromAbi(cuking_compute_king(
+        buf.ctx, &sm, words_per_sample, static_cast<uint64_t *>(buf.d_bits),
+        flags.kin_threshold, max_results, static_cast<cuking_result *>(buf.d_results),
+        d_counters, d_counters + 1, nullptr)));
+    uint32_t counters[2] = {0, 0};
+    RETURN_IF_ERROR(FromAbi(cuking_copy_to_host(buf.ctx, counters, d_counters,
+                                                sizeof(counters), nullptr)));
+    RETURN_IF_ERROR(FromAbi(cuking_stream_synchronize(buf.ctx, nullptr)));  // errors surface here
+    kernel_seconds = sw.ElapsedAndReset();
+    std::cout << " (" << std::fixed << std::setprecision(3) << kernel_seconds << "s)"
+              << std::endl;
 
-  const uint32_t num_results = counters[0];
-  std::cout << "Processing " << num_results << " results..." << std::flush;
-  std::vector<cuking_result> results(num_results);
-  RETURN_IF_ERROR(FromAbi(cuking_copy_to_host(buf.ctx, results.data(), buf.d_results,
-                                              (size_t)num_results * sizeof(cuking_result),
-                                              nullptr)));
-  RETURN_IF_ERROR(FromAbi(cuking_stream_synchronize(buf.ctx, nullptr)));
+    if (counters[1] != 0)  // cuking.cu:747-751
+      return ResourceExhausted(
+          "Could not store all results: try increasing the --max_results parameter.");
+
+    std::cout << "Processing " << counters[0] << " results..." << std::flush;
+    results.resize(counters[0]);
+    RETURN_IF_ERROR(FromAbi(cuking_copy_to_host(buf.ctx, results.data(), buf.d_results,
+                                                results.size() * sizeof(cuking_result),
+                                                nullptr)));
+    RETURN_IF_ERROR(FromAbi(cuking_stream_synchronize(buf.ctx, nullptr)));
+  }
+  const size_t num_results = results.size();
   // Free device memory before post-processing (cuking.cu:757-758).
-  cuking_device_free(buf.ctx, buf.d_bits);
-  buf.d_bits = nullptr;
+  if (buf.d_bits) {
+    cuking_device_free(buf.ctx, buf.d_bits);
+    buf.d_bits = nullptr;
+  }
   cuking_sort_results(results.data(), results.size());  // :761-765
 
   RETURN_IF_ERROR(MakeDirs(output_dir));
@@ -444,8 +542,8 @@ Status Run(const Flags &flags) {
             << rate * cuking_bytes_per_pair(words_per_sample) / 8e12
             // five plane products per pair and site on the matrix cores, 2 FLOP
             // each (the default kernel; king_mfma.hip)
-            << ", \"algorithmic_PFLOPs\": " << rate * 10.0 * metadata.num_sites / 1e15 << "}"
-            << std::endl;
+            << ", \"algorithmic_PFLOPs\": " << rate * 10.0 * metadata.num_sites / 1e15
+            << multi_summary.str() << "}" << std::endl;
   return Status::Ok();
 }
 

@@ -51,6 +51,13 @@ std::string Usage() {
          "  --device=D             GPU index (default 0)\n"
          "  --kernel=tiled|stream  device kernel (default tiled)\n"
          "  --pack=host|device     where triples are packed (default host)\n"
+         "  --num_gpus=N           share the shard among N GPUs of this node over "
+         "RCCL (default 0: one GPU, no RCCL)\n"
+         "  --multi_gpu_mode=auto|staged|simple  broadcast overlapped with compute "
+         "(diagonal shards) or broadcast then tile ranges\n"
+         "  --bcast_chunks=N       pieces the bitset broadcast is cut into (default 8)\n"
+         "  --print_schedule       diagnostic: print the multi-GPU schedule (JSON) and "
+         "exit before any GPU work\n"
          "  --dump_bitset=FILE     diagnostic: write the packed bitset (raw "
          "little-endian u64) and exit before any GPU work\n"
          "Dashes and underscores are interchangeable in flag names.\n";
@@ -123,6 +130,22 @@ std::string ParseFlags(int argc, char **argv, Flags *flags) {
     } else if (name == "dump_bitset") {
       if (!need_value()) return "Missing value for --dump_bitset";
       flags->dump_bitset = value;
+    } else if (name == "num_gpus") {
+      if (!need_value() || !ParseUnsigned(value, 64, &u))
+        return "Illegal value '" + value + "' specified for flag 'num_gpus'";
+      flags->num_gpus = (uint32_t)u;
+    } else if (name == "bcast_chunks") {
+      if (!need_value() || !ParseUnsigned(value, 1u << 20, &u) || u == 0)
+        return "Illegal value '" + value + "' specified for flag 'bcast_chunks'";
+      flags->bcast_chunks = (uint32_t)u;
+    } else if (name == "multi_gpu_mode") {
+      if (!need_value() || (value != "auto" && value != "staged" && value != "simple"))
+        return "Illegal value '" + value + "' specified for flag 'multi_gpu_mode'";
+      flags->multi_gpu_mode = value;
+    } else if (name == "print_schedule") {
+      if (has_value && value != "true" && value != "1")
+        return "Illegal value '" + value + "' specified for flag 'print_schedule'";
+      flags->print_schedule = true;
     } else if (name == "pack") {
       if (!need_value() || (value != "host" && value != "device"))
         return "Illegal value '" + value + "' specified for flag 'pack'";

@@ -27,6 +27,14 @@ struct Flags {
   std::string pack = "host";            // host | device
   std::string dump_bitset;              // diagnostic: write the packed host
                                         // bitset here and exit (no GPU used)
+  // Several GPUs of this node share the shard (multi_gpu.h).  0 = the classic
+  // one-GPU path of the reference; N >= 1 = N ranks over RCCL (N = 1 runs the
+  // same collectives on a one-rank communicator).
+  uint32_t num_gpus = 0;
+  std::string multi_gpu_mode = "auto";  // auto | staged | simple
+  uint32_t bcast_chunks = 8;
+  bool print_schedule = false;          // diagnostic: print the multi-GPU
+                                        // schedule as JSON and exit (no GPU used)
   bool help = false;
 };
 

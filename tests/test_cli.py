@@ -108,8 +108,9 @@ def test_host_code_under_asan_ubsan(tmp_path, oracle):
     exe = tmp_path / "cuking_asan"
     cmd = ["g++", "-O1", "-g", "-std=c++20", "-fsanitize=address,undefined",
            "-fno-sanitize-recover=undefined", "-pthread", f"-I{b.INCLUDE}", f"-I{b.HOST}",
-           f"-isystem{inc}", *map(str, sorted(b.HOST.glob("*.cc"))), "-o", str(exe),
-           f"-L{b.PKG}", "-l:libcuking_amd.so", f"-L{libdir}", *libs,
+           f"-isystem{inc}", *b.ROCM_HOST_FLAGS, *map(str, sorted(b.HOST.glob("*.cc"))),
+           "-o", str(exe), f"-L{b.PKG}", "-l:libcuking_amd.so", f"-L{libdir}", *libs,
+           *b.ROCM_HOST_LIBS,
            f"-Wl,-rpath,{libdir}", f"-Wl,-rpath,{b.PKG}", "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.run(cmd, check=True)
     rng = np.random.default_rng(9)
@@ -127,6 +128,45 @@ def test_host_code_under_asan_ubsan(tmp_path, oracle):
     p = subprocess.run([str(exe), "--input_uri", str(tmp_path / "none"), "--output_uri", "x",
                         "--dump_bitset", str(dump)], capture_output=True, text=True, env=env)
     assert p.returncode == 1 and "ERROR: AddressSanitizer" not in p.stderr
+
+
+# ------------------------------------------- multi-GPU scheduling (CPU) ----
+@pytest.mark.parametrize("n,k,shard,world,chunks", [
+    (1000, 1, 0, 3, 4), (10_000, 1, 0, 8, 8), (734_000, 1, 0, 8, 8), (300, 1, 0, 8, 3),
+    (129, 1, 0, 2, 8), (5000, 2, 0, 4, 5), (5000, 2, 1, 4, 5), (5000, 3, 5, 1, 2)])
+def test_multi_gpu_schedule_matches_python_driver(tmp_path, n, k, shard, world, chunks):
+    """`cuking --print_schedule` (host/schedule.h, what --num_gpus runs) ==
+    cuking_amd.dist's schedule, whose coverage of every pair exactly once is
+    brute-forced in test_dist_cpu.py; tile ranges partition the enumeration."""
+    from cuking_amd.dist import chunk_ranges, staged_schedule, tile_partition
+    d = tmp_path / "in"
+    d.mkdir()
+    (d / "metadata.json").write_text(json.dumps(
+        {"num_sites": 64, "samples": [f"s{i}" for i in range(n)]}))
+    p = run_cli("--input_uri", d, "--output_uri", tmp_path / "o", "--print_schedule",
+                f"--num_gpus={world}", f"--bcast_chunks={chunks}", f"--split_factor={k}",
+                f"--shard_index={shard}", check=True)
+    got = json.loads(p.stdout.strip().splitlines()[-1])
+    sm = cuking_amd.Submatrix(n, k, shard)
+    stored, tile = sm.NumSamples(), got["tile"]
+    assert got["world"] == world and got["stored_samples"] == stored
+    lib = cuking_amd._lib.load()
+    import ctypes as C
+    assert tile == lib.cuking_tile_samples(None)
+    assert got["num_tiles"] == lib.cuking_num_tiles(None, C.byref(sm.c))
+    assert [tuple(r) for r in got["tile_ranges"]] == tile_partition(got["num_tiles"], world)
+    assert got["tile_ranges"][0][0] == 0 and got["tile_ranges"][-1][1] == got["num_tiles"]
+    assert [tuple(c) for c in got["chunks"]] == chunk_ranges(stored, tile, chunks)
+    assert got["mode"] == ("staged" if sm.i_begin == sm.j_begin else "simple")
+    for r in range(world):
+        want = staged_schedule(stored, tile, world, r, chunks)
+        assert len(got["staged"][r]) == len(want)
+        for step, ((c0, c1), rect) in zip(got["staged"][r], want):
+            assert tuple(step["chunk"]) == (c0, c1)
+            if rect is None:
+                assert step["rows"] is None
+            else:
+                assert tuple(step["rows"]) == rect[0] and rect[1] == (c0, c1)
 
 
 # ------------------------------------------------- decode + pack (CPU) ----
@@ -399,6 +439,49 @@ def test_c0_split_factor_shards(c0, oracle):
     got = sorted(zip(t.column("i").to_pylist(), t.column("j").to_pylist()))
     assert got == sorted((c0["ids"][a], c0["ids"][b])
                          for a, b in zip(whole["sample_i"], whole["sample_j"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--num_gpus=1"], ["--num_gpus=1", "--multi_gpu_mode=simple"],
+                                   ["--num_gpus=1", "--pack=device", "--bcast_chunks=3"],
+                                   ["--num-gpus", "1", "--kernel=stream"]])
+def test_c0_through_the_rccl_path(c0, oracle, extra):
+    """`--num_gpus=1`: the multi-GPU host path with a one-rank RCCL communicator
+    -- per-rank thread, ncclCommInitAll, chunked ncclBroadcast, staged rectangle
+    launches (or a tile range), ncclAllGather of the counts, gather -- must write
+    the same file as the classic path."""
+    out = c0["dir"] / ("out_mg_" + "_".join(a.strip("-").replace("=", "_") for a in extra))
+    p = run_cli("--input-uri", c0["dir"] / "in", "--output-uri", out,
+                "--kin-threshold=0.05", "--num_reader_threads=8", *extra, check=True)
+    exp = expected_table(oracle, c0["geno"], c0["ids"], 0.05)
+    check_output(out / "part-00000.snappy.parquet", exp, c0["ids"])
+    summary = json.loads(p.stdout.strip().splitlines()[-1])
+    assert summary["gpus"] == 1 and summary["results"] == len(exp)
+    assert summary["rank_results"] == [len(exp)]
+    staged = "--multi_gpu_mode=simple" not in extra and "--kernel=stream" not in extra
+    assert summary["multi_gpu_mode"] == ("staged" if staged else "simple")
+    assert summary["bytes_broadcast"] == 1000 * cuking_amd.words_per_sample(10000) * 8
+
+
+@pytest.mark.gpu
+def test_rccl_path_shards_overflow_and_bad_gpu_count(c0, oracle):
+    # an off-diagonal shard takes the simple schedule
+    out = c0["dir"] / "out_mg_split"
+    p = run_cli("--input_uri", c0["dir"] / "in", "--output_uri", out, "--split_factor=2",
+                "--shard_index=1", "--num_gpus=1", "--kin_threshold=0.05", check=True)
+    exp = expected_table(oracle, c0["geno"], c0["ids"], 0.05, 2, 1)
+    check_output(out / "part-00001.snappy.parquet", exp, c0["ids"])
+    assert json.loads(p.stdout.strip().splitlines()[-1])["multi_gpu_mode"] == "simple"
+    # overflow is the reference's error, whatever the number of GPUs
+    p = run_cli("--input_uri", c0["dir"] / "in", "--output_uri", c0["dir"] / "out_mg_ovf",
+                "--kin_threshold=-10", "--max_results=1000", "--num_gpus=1")
+    assert p.returncode == 1
+    assert ("Error: RESOURCE_EXHAUSTED: Could not store all results: try increasing "
+            "the --max_results parameter.") in p.stderr
+    # more GPUs than the box has
+    p = run_cli("--input_uri", c0["dir"] / "in", "--output_uri", c0["dir"] / "out_mg_bad",
+                "--num_gpus=64")
+    assert p.returncode == 1 and "INVALID_ARGUMENT" in p.stderr and "GPU(s) are visible" in p.stderr
 
 
 @pytest.mark.gpu
