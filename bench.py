@@ -100,6 +100,8 @@ def parse_args():
     ap.add_argument("--kernel", default="tiled", choices=["tiled", "stream"])
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--band-rows", type=int, default=-1)
+    ap.add_argument("--xcd-swizzle", type=int, default=-1, choices=[-1, 0, 1],
+                    help="matrix-core kernel: consecutive tiles per XCD (-1 = library default)")
     ap.add_argument("--counts-mode", type=int, default=-1, choices=[-1, 0, 1],
                     help="-1 automatic, 0 lean form (4 sums + recount of emitted pairs), "
                          "1 full form (5 sums)")
@@ -205,7 +207,7 @@ def counts_form(args, thr, wps, variant):
         return "full"
     if args.counts_mode == 0:
         return "lean"
-    c = 1.9 if args.kernel == "tiled" and variant == MFMA_VARIANT else 1.6
+    c = 2.05 if args.kernel == "tiled" and variant == MFMA_VARIANT else 1.6
     return "lean" if thr > 0 and thr * thr * 32 * wps >= c * c else "full"
 
 
@@ -409,6 +411,8 @@ def main():
         ctx.set_option("band_rows", args.band_rows)
     if args.counts_mode >= 0:
         ctx.set_option("counts_mode", args.counts_mode)
+    if args.xcd_swizzle >= 0:
+        ctx.set_option("xcd_swizzle", args.xcd_swizzle)
     ctx.timing_enable(True)
     dtype_of = lambda roof: ("fp4 products, f32 accumulate (exact integers)"
                              if roof["bound"] == "mfma" else "u32")

@@ -102,8 +102,10 @@ struct cuking_ctx {
   // the same rows in every column -- and rows differ in how many of their
   // tiles are real (triangle, strided rectangles): measured 6.7 ms vs 4.3 ms
   // for a rank's strided launch (tools/rect_probe.py).
-  uint32_t band_rows = 17;
+  // 0 = by block size (band_rows_for below); tests and tuning runs pin a value.
+  uint32_t band_rows = 0;
   int counts_mode = -1;  // -1 auto, 0 lean (4 sums + recount), 1 full (5 sums)
+  int xcd_swizzle = 1;   // matrix-core kernel: consecutive tiles per XCD (king_common.h)
 
   // Workspace of the tiled kernel: the k-major planes and the band prefix.
   uint4 *planes = nullptr;
@@ -167,20 +169,20 @@ int effective_variant(const cuking_ctx *ctx, uint32_t words_per_sample) {
 // recounts hom/hom sites for every EMITTED pair; the full form keeps five sums
 // for every pair.  Measured at 10k x 100k sites: VALU kernels lean 27.8 ms +
 // 3 ms per 10^6 emitted pairs against full 34.4 ms flat; matrix-core kernel
-// lean 7.0 ms + 10 ms per 10^6 emitted pairs against full 10.3 ms + 0.9 ms per
-// 10^6 (two passes over k).  For unrelated samples kinship scatters around 0
-// with a spread ~ 1/sqrt(sites) (at 100k sites 2 % of the pairs exceed 0.005,
-// 0.3 % exceed 0.007), so the automatic choice is lean iff
-// kin_threshold > c / sqrt(sites) with c = 1.6 (VALU) or 1.9 (matrix cores:
-// break-even near 0.7 % of the pairs emitted).  Either form gives the same
-// records.
+// lean 7.0 ms + 10 ms per 10^6 emitted pairs against full 8.8 ms + 0.9 ms per
+// 10^6 (the fifth sum in a pass of its own, king_mfma.hip).  For unrelated
+// samples kinship scatters around 0 with a spread ~ 1/sqrt(sites) (at 100k
+// sites 2 % of the pairs exceed 0.005, 0.3 % exceed 0.007), so the automatic
+// choice is lean iff kin_threshold > c / sqrt(sites) with c = 1.6 (VALU) or
+// 2.05 (matrix cores: break-even near 0.4 % of the pairs emitted).  Either
+// form gives the same records.
 bool use_full_counts(const cuking_ctx *ctx, float kin_threshold, bool dense,
                      uint32_t words_per_sample) {
   if (dense || ctx->counts_mode == 1) return true;
   if (ctx->counts_mode == 0) return false;
   if (!(kin_threshold > 0.0f)) return true;
   const double sites = 32.0 * words_per_sample;
-  const double c = effective_variant(ctx, words_per_sample) == kMfmaVariant ? 1.9 : 1.6;
+  const double c = effective_variant(ctx, words_per_sample) == kMfmaVariant ? 2.05 : 1.6;
   return (double)kin_threshold * kin_threshold * sites < c * c;
 }
 
@@ -205,8 +207,23 @@ PlaneGeometry make_geometry(const cuking_submatrix &sm,
   return g;
 }
 
+// Band height when the caller has not pinned one.  Measured on MI355X with the
+// XCD-aware order (profiles/r02_xcd_order.txt): the matrix-core kernel wants
+// the 32 tiles an XCD holds at a time to be a compact patch, 5 rows x ~6
+// columns (11 strips through one L2 instead of 32): 100k x 100k 645 -> 621 ms,
+// 300k x 150k 9.33 -> 8.69 s.  Below ~128 tile rows the bitset sits in the
+// Infinity Cache anyway and 17 rows measured 2-3 % better (10k samples:
+// 7.04 -> 6.77 ms with the XCD order, 6.96 with 5 rows).  The VALU kernels
+// keep 17 (see cuking_ctx::band_rows in the round-1 notes, tools/rect_probe.py).
+uint32_t band_rows_for(uint32_t pinned, const PlaneGeometry &g, const TiledVariant &v) {
+  if (pinned != 0) return pinned;
+  if (v.layout != kLayoutQuad) return 17;
+  return g.rows_padded / v.tile >= 128 ? 5 : 17;
+}
+
 TileSpace make_tiles(const PlaneGeometry &g, const TiledVariant &v,
                      uint32_t band_rows) {
+  band_rows = band_rows_for(band_rows, g, v);
   TileSpace t;
   t.tiles_r = g.rows_padded / v.tile;
   t.tiles_c = g.cols_padded / v.tile;
@@ -466,6 +483,8 @@ cuking_status run_tiled(cuking_ctx *ctx, const cuking_submatrix &sm,
   a.split_tiles = 0;
   a.split_whole = 0;
   a.split_wgs = ctx->split_wgs;
+  a.xcd_chunk = ctx->xcd_swizzle ? 1u : 0u;  // (switch; the launch sets the value)
+  a.launch_tiles = 0;
   st = split_scratch_for(ctx, stream, &a.split_scratch, &a.split_counters);
   if (st != CUKING_OK) return st;
 
@@ -650,6 +669,7 @@ cuking_status cuking_ctx_create(int device, cuking_ctx **out) {
     const int k = atoi(v);
     if (k >= 0 && k <= 4096) ctx->split_wgs = (uint32_t)k;
   }
+  if (const char *v = getenv("CUKING_AMD_XCD_SWIZZLE")) ctx->xcd_swizzle = atoi(v) != 0;
   if (const char *v = getenv("CUKING_AMD_BAND_ROWS")) {
     const int k = atoi(v);
     if (k >= 1 && k <= 64) ctx->band_rows = (uint32_t)k;
@@ -691,8 +711,8 @@ cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
     return CUKING_OK;
   }
   if (strcmp(key, "band_rows") == 0) {
-    if (value < 1 || value > 64)
-      return fail(CUKING_ERR_INVALID_ARGUMENT, "band_rows outside [1, 64]");
+    if (value < 0 || value > 64)
+      return fail(CUKING_ERR_INVALID_ARGUMENT, "band_rows outside [0, 64]");
     ctx->band_rows = (uint32_t)value;
     return CUKING_OK;
   }
@@ -711,6 +731,12 @@ cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
   if (strcmp(key, "max_launch_blocks") == 0) {  // test hook, process-wide
     if (value < 0) return fail(CUKING_ERR_INVALID_ARGUMENT, "negative block cap");
     set_max_blocks_per_launch((uint64_t)value);
+    return CUKING_OK;
+  }
+  if (strcmp(key, "xcd_swizzle") == 0) {
+    if (value < 0 || value > 1)
+      return fail(CUKING_ERR_INVALID_ARGUMENT, "xcd_swizzle outside [0, 1]");
+    ctx->xcd_swizzle = (int)value;
     return CUKING_OK;
   }
   if (strcmp(key, "counts_mode") == 0) {
@@ -851,7 +877,7 @@ uint64_t cuking_num_tiles(const cuking_ctx *ctx, const cuking_submatrix *sm) {
   const TiledVariant &v = tiled_variant(ctx ? ctx->variant : default_variant());
   const PlaneGeometry g = make_geometry(*sm, 2, v);
   if (g.num_rows == 0 || g.num_cols == 0) return 0;
-  return total_tiles(make_tiles(g, v, ctx ? ctx->band_rows : 17));
+  return total_tiles(make_tiles(g, v, ctx ? ctx->band_rows : 0));
 }
 
 cuking_status cuking_tile_bounds(const cuking_ctx *ctx,
@@ -862,7 +888,7 @@ cuking_status cuking_tile_bounds(const cuking_ctx *ctx,
   if (st != CUKING_OK) return st;
   const TiledVariant &v = tiled_variant(ctx ? ctx->variant : default_variant());
   const PlaneGeometry g = make_geometry(*sm, 2, v);
-  const TileSpace ts = make_tiles(g, v, ctx ? ctx->band_rows : 17);
+  const TileSpace ts = make_tiles(g, v, ctx ? ctx->band_rows : 0);
   if (g.num_rows == 0 || g.num_cols == 0 || tile >= total_tiles(ts))
     return fail(CUKING_ERR_INVALID_ARGUMENT, "tile index out of range");
   uint32_t b = 0;
@@ -887,6 +913,7 @@ cuking_status cuking_ctx_get_option(const cuking_ctx *ctx, const char *key,
   else if (strcmp(key, "split_wgs") == 0) *value = ctx->split_wgs;
   else if (strcmp(key, "band_rows") == 0) *value = ctx->band_rows;
   else if (strcmp(key, "counts_mode") == 0) *value = ctx->counts_mode;
+  else if (strcmp(key, "xcd_swizzle") == 0) *value = ctx->xcd_swizzle;
   else return fail(CUKING_ERR_INVALID_ARGUMENT, "unknown option %s", key);
   return CUKING_OK;
 }
@@ -1075,6 +1102,8 @@ cuking_status cuking_compute_king_rect(
   a.split_tiles = 0;
   a.split_whole = 0;
   a.split_wgs = ctx->split_wgs;
+  a.xcd_chunk = ctx->xcd_swizzle ? 1u : 0u;
+  a.launch_tiles = 0;
   st = split_scratch_for(ctx, (hipStream_t)stream, &a.split_scratch, &a.split_counters);
   if (st != CUKING_OK) return st;
   EventPair *ev = nullptr;

@@ -127,6 +127,13 @@ struct TiledArgs {
   // whole tile each (tiles tile_begin .. tile_begin + split_whole - 1).
   uint32_t split_whole;
   uint32_t *split_scratch, *split_counters;
+  // XCD-aware order (matrix-core kernel, whole-tile launches): workgroups are
+  // dealt round-robin over the 8 XCDs, each with its own L2; with xcd_chunk != 0
+  // workgroup b takes tile (b % 8) * xcd_chunk + b / 8 of the launch's
+  // launch_tiles, so that the workgroups resident on one XCD at a time hold
+  // CONSECUTIVE tiles of the band order (few row/column strips per L2) instead
+  // of every eighth one.
+  uint32_t xcd_chunk, launch_tiles;
 };
 
 // Bytes of the plane workspace for a geometry.
@@ -161,6 +168,9 @@ constexpr int kMfmaVariant = 5;
 #define CUKING_MFMA_STAGES 6
 #endif
 constexpr uint32_t kMfmaLdsBytes = CUKING_MFMA_STAGES * 2 * 2 * 2 * 128 * 16;
+// The full form parks its fifth sum (64 registers per lane) behind the stages.
+constexpr uint32_t kMfmaParkBytes = 4 * 64 * 64 * 4;
+static_assert(kMfmaLdsBytes + kMfmaParkBytes <= 160 * 1024, "LDS of one CU");
 const TiledVariant &tiled_variant(int v);
 // Enqueues tiles [args.tile_begin, args.tile_begin + num_tiles).
 // full = accumulate all five sums for every pair (needed for the diagnostic

@@ -150,8 +150,9 @@ __device__ __forceinline__ uint32_t split_owner(uint64_t u, uint64_t units,
 template <bool FULL, bool SPLIT, int ABLATE = 0>
 __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   constexpr int NSTAGE = kStages;
-  constexpr int NQ = FULL ? 5 : 4;
-  constexpr int BI = FULL ? 1 : 2;  // 32-row blocks per pass over k
+  constexpr int NQ = 4;              // sums of the main loop: opp, bh, hi, hj
+  constexpr int NSUM = FULL ? 5 : 4; // + hom_hom from the full form's second pass
+  constexpr int BI = 2;              // 32-row blocks of the wavefront
   extern __shared__ uint4 lds[];  // [NSTAGE][side][k-group][plane][128]
 
   const uint32_t lane = threadIdx.x & 63;
@@ -178,9 +179,14 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   // into equal pieces (piece index `piece`).
   const uint64_t units = (uint64_t)a.split_tiles * tile_steps;      // of the cut-up tiles
   const uint64_t whole_units = SPLIT ? (uint64_t)a.split_whole * tile_steps : 0;
+  uint32_t bid = blockIdx.x;
+  if (!SPLIT && a.xcd_chunk != 0) {
+    bid = (blockIdx.x & 7) * a.xcd_chunk + (blockIdx.x >> 3);
+    if (bid >= a.launch_tiles) return;  // padding of the last chunk (uniform)
+  }
   const bool whole_wg = !SPLIT || blockIdx.x < a.split_whole;
   const uint32_t piece = SPLIT && !whole_wg ? blockIdx.x - a.split_whole : 0;
-  uint64_t unit_lo = whole_wg ? (uint64_t)blockIdx.x * tile_steps
+  uint64_t unit_lo = whole_wg ? (uint64_t)bid * tile_steps
                               : whole_units + split_bound(piece, units, a.split_wgs);
   uint64_t unit_hi = whole_wg ? unit_lo + tile_steps
                               : whole_units + split_bound(piece + 1, units, a.split_wgs);
@@ -201,14 +207,27 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     unit_hi = unit_lo + tile_steps;
     next_tile += gridDim.x;
   }
-  const uint32_t seg_tile = (uint32_t)(unit_lo / tile_steps);  // within the launch
-  const uint32_t k_first = (uint32_t)(unit_lo - (uint64_t)seg_tile * tile_steps);
-  const uint32_t num_steps = (unit_hi - unit_lo < (uint64_t)(tile_steps - k_first))
-                                 ? (uint32_t)(unit_hi - unit_lo)
-                                 : tile_steps - k_first;
+  // Everything about the piece is wave-uniform; the 64-bit divisions behind it
+  // are computed in vector registers, so pin the results to SGPRs (the SPLIT
+  // instantiation otherwise runs out of VGPRs in the main loop and spills).
+  const uint32_t seg_tile =
+      __builtin_amdgcn_readfirstlane((uint32_t)(unit_lo / tile_steps));  // within the launch
+  const uint32_t k_first = __builtin_amdgcn_readfirstlane(
+      (uint32_t)(unit_lo - (uint64_t)seg_tile * tile_steps));
+  const uint32_t num_steps = __builtin_amdgcn_readfirstlane(
+      (unit_hi - unit_lo < (uint64_t)(tile_steps - k_first)) ? (uint32_t)(unit_hi - unit_lo)
+                                                             : tile_steps - k_first);
   unit_lo += num_steps;
+  if (SPLIT) {
+    unit_lo = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(unit_lo >> 32)) << 32) |
+              __builtin_amdgcn_readfirstlane((uint32_t)unit_lo);
+    unit_hi = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(unit_hi >> 32)) << 32) |
+              __builtin_amdgcn_readfirstlane((uint32_t)unit_hi);
+  }
   uint32_t tr, tc;
   if (!decode_tile(a, a.tile_begin + seg_tile, &tr, &tc)) continue;  // uniform
+  tr = __builtin_amdgcn_readfirstlane(tr);
+  tc = __builtin_amdgcn_readfirstlane(tc);
 
   const uint4 *g_rows = a.planes + (uint64_t)tr * kTile;
   const uint4 *g_cols = a.planes + a.geo.col_base + (uint64_t)tc * kTile;
@@ -219,11 +238,11 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   // whole loop; the repeats of the last step land in a buffer nobody reads.
   auto issue_piece = [&](uint32_t step, uint32_t buf, int r) {
     if (ABLATE == 1 || ABLATE == 2) return;
-    if (step >= num_steps) step = num_steps - 1;
-    step += k_first;
     const uint32_t row = wave * kPiecesPerWave + r;  // 1 KiB row of the stage, 0..15
     const uint32_t side = row >> 3, kg = (row >> 2) & 1;
     const uint32_t p = (row >> 1) & 1, seg = row & 1;
+    if (step >= num_steps) step = num_steps - 1;
+    step += k_first;
     // Wave-uniform source row (SGPR pair) + one per-lane byte offset: no
     // per-request address arithmetic in vector registers.
     const uint4 *src = (side ? g_cols : g_rows) +
@@ -255,11 +274,120 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     __syncthreads();
   };
 
-  // The full form's five sums for 2 x 2 blocks would need 320 accumulator
-  // registers: it makes two passes over k, one per 32-row block (BI = 1), which
-  // fits without spills; the lean form does its 2 x 2 blocks in one pass.
-  for (uint32_t half = 0; half < (FULL ? 2u : 1u); ++half) {
-  const uint32_t half_rows = half * 32;
+  // Full form: the fifth sum, hom_hom = (A|R)_i . (A|R)_j, in a pass of its own
+  // IN FRONT of the main loop.  Five sums for 2 x 2 blocks are 320 accumulator
+  // registers, more than the main loop can hold beside its fragments; but
+  // "homozygous and defined" is just ~het (missing and padding have the het bit
+  // set, cuking.cu:688-697), so this pass reads ONE plane, builds one fragment
+  // kind per side and issues 16 MFMAs per k-step against the main loop's 80.
+  // With so few MFMAs per byte the LDS-DMA requests and stage barriers of the
+  // main loop would dominate (measured: 1.9 ms of 8.8 at 10k x 100k), so every
+  // lane fetches its own operand words straight from the plane layout into
+  // registers, four k-steps ahead (512 B contiguous per half wavefront; each
+  // word is read by two wavefronts, from L2): no LDS, no barrier, the
+  // wavefronts drift freely.  The 64 result registers per lane are parked in
+  // the 64 KiB of LDS behind the stages until the epilogue (the workgroup owns
+  // the CU's whole 160 KiB anyway), so the main loop runs exactly as in the
+  // lean form.  (Round 1's full form made two passes of six products over
+  // 32-row blocks in the compiler's order: 10.3 ms at 10k x 100k against 7.0 ms
+  // lean.)
+  if constexpr (FULL) {
+    constexpr int D = 4;  // k-steps in flight
+    v16f hh[BI][2];
+#pragma unroll
+    for (int bi = 0; bi < BI; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hh[bi][bj][r] = 0.f;
+    const uint4 *lane_rows = g_rows + (uint64_t)g * 2 * s_stride + wr + lr;
+    const uint4 *lane_cols = g_cols + (uint64_t)g * 2 * s_stride + wc + lr;
+    uint4 Ha[D][BI], Hb[D][2], Hs_a[BI], Hs_b[2];
+    v8i Pa[BI], Pb[2], Qa[BI], Qb[2];
+    // het words of k-step min(step, last) (the repeats are masked out below)
+#define CUKING_HH_LOAD(U, STEP)                                                \
+    {                                                                          \
+      uint32_t s_ = (STEP);                                                    \
+      if (s_ >= num_steps) s_ = num_steps - 1;                                 \
+      const uint64_t off_ = (uint64_t)(s_ + k_first) * 4 * s_stride;           \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b) {                          \
+        Ha[U][b] = lane_rows[off_ + b * 32];                                   \
+        Hb[U][b] = lane_cols[off_ + b * 32];                                   \
+      }                                                                        \
+    }
+#define CUKING_HH_FRAGS(X, SA, SB, MASK)                                       \
+    _Pragma("unroll") for (int b = 0; b < 2; ++b) {                            \
+      X##a[b] = frag<kY>(SA[b], SA[b], MASK);                                  \
+      X##b[b] = frag<kY>(SB[b], SB[b], MASK);                                  \
+    }
+#define CUKING_HH_MMA(F, X)                                                    \
+    _Pragma("unroll") for (int bi = 0; bi < BI; ++bi)                          \
+    _Pragma("unroll") for (int bj = 0; bj < 2; ++bj)                           \
+      hh[bi][bj] = mma<F>(X##a[bi], X##b[bj], hh[bi][bj]);
+    // One k-step in four phases; while the four MFMAs of a phase issue, the
+    // VALU builds the next phase's fragments into the other register set (the
+    // last phase builds position 0 of the NEXT k-step, buffer UN).  A k-step
+    // beyond the end gets zero masks: its fragments are empty.
+#define CUKING_HH_KSTEP(U, UN)                                                 \
+    {                                                                          \
+      const bool live_ = step + (U) < num_steps;                               \
+      const bool next_ = step + (U) + 1 < num_steps;                           \
+      const uint32_t k2_ = live_ ? m2 : 0u, k4_ = live_ ? m4 : 0u;             \
+      const uint32_t k1_ = live_ ? m1 : 0u, n1_ = next_ ? m1 : 0u;             \
+      CUKING_HH_FRAGS(Q, Ha[U], Hb[U], k2_)                                    \
+      CUKING_HH_MMA(0, P)                                                      \
+      CUKING_PACE(4, 4)                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                       \
+      CUKING_HH_FRAGS(P, Ha[U], Hb[U], k4_)                                    \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b) {                          \
+        Hs_a[b] = shr3(Ha[U][b]);                                              \
+        Hs_b[b] = shr3(Hb[U][b]);                                              \
+      }                                                                        \
+      CUKING_HH_MMA(1, Q)                                                      \
+      CUKING_PACE(4, 8)                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                       \
+      CUKING_HH_FRAGS(Q, Hs_a, Hs_b, k1_)                                      \
+      CUKING_HH_MMA(2, P)                                                      \
+      CUKING_PACE(4, 4)                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                       \
+      CUKING_HH_LOAD(U, step + D + (U))                                        \
+      CUKING_HH_FRAGS(P, Ha[UN], Hb[UN], n1_)                                  \
+      CUKING_HH_MMA(3, Q)                                                      \
+      CUKING_PACE(4, 4)                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                       \
+    }
+    CUKING_HH_LOAD(0, 0)
+    CUKING_HH_LOAD(1, 1)
+    CUKING_HH_LOAD(2, 2)
+    CUKING_HH_LOAD(3, 3)
+    CUKING_HH_FRAGS(P, Ha[0], Hb[0], m1)
+    for (uint32_t step = 0; step < num_steps; step += D) {
+      CUKING_HH_KSTEP(0, 1)
+      CUKING_HH_KSTEP(1, 2)
+      CUKING_HH_KSTEP(2, 3)
+      CUKING_HH_KSTEP(3, 0)
+    }
+#undef CUKING_HH_LOAD
+#undef CUKING_HH_FRAGS
+#undef CUKING_HH_MMA
+#undef CUKING_HH_KSTEP
+    float4 *park = reinterpret_cast<float4 *>(lds + NSTAGE * kStageU4) +
+                   (size_t)wave * (4 * 4 * 64) + lane;
+#pragma unroll
+    for (int bi = 0; bi < BI; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+          park[((bi * 2 + bj) * 4 + r4) * 64] =
+              make_float4(hh[bi][bj][4 * r4], hh[bi][bj][4 * r4 + 1], hh[bi][bj][4 * r4 + 2],
+                          hh[bi][bj][4 * r4 + 3]);
+    // (the prefetches beyond the end are in registers nobody reads; the
+    //  compiler's own wait counts cover them before the main loop's hand-counted
+    //  LDS-DMA starts: force that here)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  }
+
   v16f acc[BI][2][NQ];
 #pragma unroll
   for (int bi = 0; bi < BI; ++bi)
@@ -269,6 +397,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[bi][bj][q][r] = 0.f;
+  constexpr uint32_t half_rows = 0;
 
   // Raw words of the k-step: [block][plane] for the row and the column side.
   uint4 A[BI][2], B[2][2];
@@ -313,42 +442,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   for (int st = 0; st < NSTAGE - 1; ++st) issue_stage(st, st);
   stage_sync();
 
-  if constexpr (FULL) {
-    // One row block, five sums, six products: plain loop, the compiler's order.
-    uint32_t buf = 0;
-    asm volatile("" : "+v"(row_off), "+v"(col_off), "+v"(lane16));
-    for (uint32_t step = 0; step < num_steps; ++step) {
-      if (step != 0) stage_sync();
-      issue_stage(step + NSTAGE - 1, buf == 0 ? NSTAGE - 1 : buf - 1);
-      CUKING_LOAD_RAW(buf)
-      uint4 As[BI][2], Bs[2][2];
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-#pragma unroll
-        for (int b = 0; b < BI; ++b) As[b][p] = shr3(A[b][p]);
-#pragma unroll
-        for (int b = 0; b < 2; ++b) Bs[b][p] = shr3(B[b][p]);
-      }
-#define CUKING_FULL_STEP(F, SA, SB, MASK)                                      \
-      {                                                                        \
-        v8i Xa[BI][4], Xb[2][4];                                               \
-        CUKING_EXPAND(X, SA, SB, MASK)                                         \
-        CUKING_MMA16(F, X)                                                     \
-        CUKING_MMA4(F, X)                                                      \
-        _Pragma("unroll") for (int bi = 0; bi < BI; ++bi)                      \
-        _Pragma("unroll") for (int bj = 0; bj < 2; ++bj)                       \
-          acc[bi][bj][NQ - 1] =                                                \
-              mma<F>(frag<kY>(SA[bi][0], SA[bi][1], MASK),                     \
-                     frag<kY>(SB[bj][0], SB[bj][1], MASK), acc[bi][bj][NQ - 1]); \
-      }
-      CUKING_FULL_STEP(0, A, B, m1)
-      CUKING_FULL_STEP(1, A, B, m2)
-      CUKING_FULL_STEP(2, A, B, m4)
-      CUKING_FULL_STEP(3, As, Bs, m1)
-#undef CUKING_FULL_STEP
-      if (++buf == NSTAGE) buf = 0;
-    }
-  } else {
+  {
     // Software pipeline: while the MFMAs of fragment f issue, the VALU builds
     // fragment f + 1 into the other register set (an MFMA never reads a
     // register written just before it); behind the MFMAs of f = 3 come the
@@ -434,6 +528,11 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   // workgroup's LDS goes away.
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   if (SPLIT) __syncthreads();  // ... and nobody reads the stages any more
+
+  // Full form: the fifth sum stays where the pass in front of the main loop
+  // parked it (this lane's 16-byte slots) and is read block by block.
+  float4 *const park = reinterpret_cast<float4 *>(lds + NSTAGE * kStageU4) +
+                       (size_t)wave * (4 * 4 * 64) + lane;
 #undef CUKING_LOAD_RAW
 #undef CUKING_EXPAND
 #undef CUKING_MMA1
@@ -444,18 +543,17 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     // Partial tile: park this part in its own slab (16-byte stores,
     // lane-linear [wave][block pair][sum][4 registers][lane]), then take a
     // ticket of the tile.  Slab of a part: 2 * workgroup + (0 for the piece in
-    // the workgroup's first tile, 1 for the piece in its second); the full
-    // form's two passes use the two halves of the slab and a ticket each.
-    constexpr size_t kSlabU4 = 4 * 4 * 4 * 4 * 64;        // uint4 per slab (lean)
-    constexpr size_t kPassU4 = 4 * BI * 2 * NQ * 4 * 64;  // ... per pass
-    static_assert(kPassU4 * (FULL ? 2 : 1) <= kSlabU4 * 5 / 4, "slab size");
+    // the workgroup's first tile, 1 for the piece in its second).
+    constexpr size_t kSlabU4 = 4 * 4 * 4 * 4 * 64;          // uint4 per slab (lean)
+    constexpr size_t kPassU4 = 4 * BI * 2 * NSUM * 4 * 64;  // ... of this form
+    static_assert(kPassU4 <= kSlabU4 * 5 / 4, "slab size");
     // (positions inside the cut-up part of the launch: tile and units count
     // from its first tile)
     const uint32_t cut_tile = seg_tile - a.split_whole;
     const uint64_t first_unit = (uint64_t)cut_tile * tile_steps;
     const uint64_t my_first = split_bound(piece, units, a.split_wgs);
     const uint32_t my_slab = 2 * piece + (my_first / tile_steps == cut_tile ? 0 : 1);
-    float4 *slabs = reinterpret_cast<float4 *>(a.split_scratch) + half * kPassU4;
+    float4 *slabs = reinterpret_cast<float4 *>(a.split_scratch);
     constexpr size_t kSlabStride = kSlabU4 * 5 / 4;  // sized for the full form
     {
       // Write-through (sc1) 16-byte stores: the data is in memory when the
@@ -464,22 +562,30 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       typedef uint32_t v4u __attribute__((ext_vector_type(4)));
       const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
           slabs + my_slab * kSlabStride, 0, (int)(kPassU4 * 16), 0x00020000);
-      const int base = (int)((wave * (BI * 2 * NQ * 4 * 64) + lane) * 16);
+      const int base = (int)((wave * (BI * 2 * NSUM * 4 * 64) + lane) * 16);
 #pragma unroll
       for (int bi = 0; bi < BI; ++bi)
 #pragma unroll
         for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
-          for (int q = 0; q < NQ; ++q)
+          for (int q = 0; q < NSUM; ++q)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
               v4u v;
-              v[0] = __float_as_uint(acc[bi][bj][q][4 * r4]);
-              v[1] = __float_as_uint(acc[bi][bj][q][4 * r4 + 1]);
-              v[2] = __float_as_uint(acc[bi][bj][q][4 * r4 + 2]);
-              v[3] = __float_as_uint(acc[bi][bj][q][4 * r4 + 3]);
+              if (q < NQ) {
+                v[0] = __float_as_uint(acc[bi][bj][q][4 * r4]);
+                v[1] = __float_as_uint(acc[bi][bj][q][4 * r4 + 1]);
+                v[2] = __float_as_uint(acc[bi][bj][q][4 * r4 + 2]);
+                v[3] = __float_as_uint(acc[bi][bj][q][4 * r4 + 3]);
+              } else {
+                const float4 h = park[((bi * 2 + bj) * 4 + r4) * 64];
+                v[0] = __float_as_uint(h.x);
+                v[1] = __float_as_uint(h.y);
+                v[2] = __float_as_uint(h.z);
+                v[3] = __float_as_uint(h.w);
+              }
               __builtin_amdgcn_raw_buffer_store_b128(
-                  v, rsrc, base + ((((bi * 2 + bj) * NQ + q) * 4 + r4) * 64) * 16, 0,
+                  v, rsrc, base + ((((bi * 2 + bj) * NSUM + q) * 4 + r4) * 64) * 16, 0,
                   16 /* sc1 */);
             }
     }
@@ -493,7 +599,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     if (threadIdx.x == 0) {
       // One counter per workgroup (and pass): a workgroup owns the first unit
       // of at most one tile that continues into the next workgroup.
-      uint32_t *counter = a.split_counters + half * a.split_wgs + w_first;
+      uint32_t *counter = a.split_counters + w_first;
       const uint32_t ticket = __hip_atomic_fetch_add(
           counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const bool last = ticket == w_last - w_first;
@@ -514,20 +620,25 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       const uint32_t slab =
           2 * w + (split_bound(w, units, a.split_wgs) / tile_steps == cut_tile ? 0 : 1);
       const float4 *src =
-          slabs + slab * kSlabStride + (size_t)wave * (BI * 2 * NQ * 4 * 64) + lane;
+          slabs + slab * kSlabStride + (size_t)wave * (BI * 2 * NSUM * 4 * 64) + lane;
 #pragma unroll
       for (int bi = 0; bi < BI; ++bi)
 #pragma unroll
         for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
-          for (int q = 0; q < NQ; ++q)
+          for (int q = 0; q < NSUM; ++q)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-              const float4 v = src[(((bi * 2 + bj) * NQ + q) * 4 + r4) * 64];
-              acc[bi][bj][q][4 * r4] += v.x;
-              acc[bi][bj][q][4 * r4 + 1] += v.y;
-              acc[bi][bj][q][4 * r4 + 2] += v.z;
-              acc[bi][bj][q][4 * r4 + 3] += v.w;
+              const float4 v = src[(((bi * 2 + bj) * NSUM + q) * 4 + r4) * 64];
+              if (q < NQ) {
+                acc[bi][bj][q][4 * r4] += v.x;
+                acc[bi][bj][q][4 * r4 + 1] += v.y;
+                acc[bi][bj][q][4 * r4 + 2] += v.z;
+                acc[bi][bj][q][4 * r4 + 3] += v.w;
+              } else {
+                float4 &h = park[((bi * 2 + bj) * 4 + r4) * 64];
+                h = make_float4(h.x + v.x, h.y + v.y, h.z + v.z, h.w + v.w);
+              }
             }
     }
   }
@@ -542,6 +653,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
           for (int r = 0; r < 16; ++r) sum += acc[bi][bj][q][r];
+    if (FULL) sum += park[0].x;
     if (sum == -1.f) a.results[0].kin = sum;  // never true, keeps the sums alive
     continue;
   }
@@ -553,6 +665,15 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
 #pragma unroll
     for (int bj = 0; bj < 2; ++bj) {
       const uint32_t lj = tc * kTile + wc + bj * 32 + lr;
+      float hh[16];  // (full form) hom_hom of this block's 16 pairs
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const float4 h = FULL ? park[((bi * 2 + bj) * 4 + r4) * 64] : make_float4(0, 0, 0, 0);
+        hh[4 * r4] = h.x;
+        hh[4 * r4 + 1] = h.y;
+        hh[4 * r4 + 2] = h.z;
+        hh[4 * r4 + 3] = h.w;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const uint32_t li =
@@ -563,7 +684,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
         if (FULL) {
           full_epilogue_pair(a, valid, li, lj, (uint32_t)acc[bi][bj][2][r],
                              (uint32_t)acc[bi][bj][3][r], (uint32_t)acc[bi][bj][1][r],
-                             (uint32_t)acc[bi][bj][0][r], (uint32_t)acc[bi][bj][NQ - 1][r]);
+                             (uint32_t)acc[bi][bj][0][r], (uint32_t)hh[r]);
         } else {
           // Nearly every pair fails the threshold: decide that on the float
           // sums without the IEEE divide, and only when some lane of the
@@ -581,8 +702,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       }
     }
   }
-  if (SPLIT || FULL) __syncthreads();  // LDS is reused by the next pass / piece
-  }  // passes (full form: two)
+  if (SPLIT) __syncthreads();  // LDS is reused by the next piece
   }  // pieces of this workgroup
 }
 
@@ -590,6 +710,7 @@ template <bool FULL, bool SPLIT, int ABLATE = 0>
 hipError_t launch_shape(const TiledArgs &args, uint64_t num_blocks,
                         uint32_t lds_bytes, hipStream_t stream) {
   auto kernel = king_mfma_kernel<FULL, SPLIT, ABLATE>;
+  if (FULL) lds_bytes += kMfmaParkBytes;  // the parked fifth sum, behind the stages
   static DeviceOnce attr_set;  // per device, see king_device.h
   if (!attr_set.done()) {
     hipError_t e = hipFuncSetAttribute(
@@ -602,13 +723,24 @@ hipError_t launch_shape(const TiledArgs &args, uint64_t num_blocks,
     kernel<<<dim3((uint32_t)num_blocks), dim3(256), lds_bytes, stream>>>(args);
     return hipGetLastError();
   }
-  const uint64_t cap = max_blocks_per_launch(256);
+  // (the XCD order pads a launch to a multiple of 8 workgroups)
+  uint64_t cap = max_blocks_per_launch(256);
+  const bool xcd_order = args.xcd_chunk != 0 && cap >= 64;
+  if (xcd_order) cap &= ~7ull;
   uint64_t done = 0;
   while (done < num_blocks) {
     const uint64_t n = (num_blocks - done < cap) ? num_blocks - done : cap;
     TiledArgs a = args;
     a.tile_begin = args.tile_begin + done;
-    kernel<<<dim3((uint32_t)n), dim3(256), lds_bytes, stream>>>(a);
+    uint64_t grid = n;
+    if (xcd_order && n >= 64) {
+      a.xcd_chunk = (uint32_t)((n + 7) / 8);
+      a.launch_tiles = (uint32_t)n;
+      grid = 8ull * a.xcd_chunk;
+    } else {
+      a.xcd_chunk = 0;
+    }
+    kernel<<<dim3((uint32_t)grid), dim3(256), lds_bytes, stream>>>(a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     done += n;

@@ -154,15 +154,19 @@ cuking_status cuking_ctx_set_kernel(cuking_ctx *ctx, cuking_kernel kernel);
  * matrix-core variant, 0..4 are VALU AND/popcount shapes), "split_wgs"
  * (matrix-core variant: short launches cut their remainder of tiles into this
  * many equal pieces, default one per CU, 0 = never), "band_rows"
- * (tile-rows per scheduling band, 1..64; env CUKING_AMD_BAND_ROWS) and
+ * (tile-rows per scheduling band, 1..64, 0 = chosen by block size, the default;
+ * env CUKING_AMD_BAND_ROWS), "xcd_swizzle" (matrix-core variant: 1 = the
+ * workgroups resident on one XCD hold consecutive tiles of the band order,
+ * default; env CUKING_AMD_XCD_SWIZZLE) and
  * "counts_mode" (0 = lean: four sums per pair in the main loop, the hom/hom
  * count behind IBS2 recounted only for emitted pairs; 1 = full: all five sums
- * for every pair; -1 = automatic: lean when kin_threshold > c / sqrt(sites), c = 1.9 (1.6 for the VALU variants),
+ * for every pair; -1 = automatic: lean when kin_threshold > c / sqrt(sites), c = 2.05 (1.6 for the VALU variants),
  * i.e. when few pairs are expected to pass).  Results do
  * not depend on any of them. */
 cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
                                     int64_t value);
-/* Current value of "variant", "split_wgs", "band_rows" or "counts_mode". */
+/* Current value of "variant", "split_wgs", "band_rows", "xcd_swizzle" or
+ * "counts_mode". */
 cuking_status cuking_ctx_get_option(const cuking_ctx *ctx, const char *key,
                                     int64_t *value);
 int cuking_num_variants(void);

@@ -426,7 +426,9 @@ def test_options_round_trip(ctx):
     try:
         assert fresh.get_option("variant") == 5 and fresh.variant_name() == "t128_mfma_fp4"
         assert fresh.get_option("split_wgs") > 0 and fresh.get_option("counts_mode") == -1
-        for key, value in (("variant", 2), ("band_rows", 9), ("counts_mode", 1), ("split_wgs", 0)):
+        assert fresh.get_option("xcd_swizzle") == 1 and fresh.get_option("band_rows") == 0
+        for key, value in (("variant", 2), ("band_rows", 9), ("counts_mode", 1), ("split_wgs", 0),
+                           ("xcd_swizzle", 0)):
             fresh.set_option(key, value)
             assert fresh.get_option(key) == value
         assert fresh.tile_samples() == 128
@@ -795,3 +797,46 @@ def test_calls_on_two_streams_of_one_context(ctx, oracle, variant):
             got = cuking_amd.sort_results(res[:cnt].cpu().numpy().view(np.uint32).reshape(
                 -1).view(cuking_amd.KING_RESULT_DTYPE).copy())
             assert ovf == 0 and got.tobytes() == exp.tobytes(), rounds
+
+
+@pytest.mark.parametrize("split_wgs", [0, 256])
+def test_tile_order_options_do_not_change_results(ctx, oracle, split_wgs):
+    """XCD-aware workgroup order and band height only permute which workgroup
+    evaluates which tile: records, tile-range unions and rectangles stay the
+    oracle's for every setting (launches of >= 64 tiles take the XCD order)."""
+    select(ctx, "tiled", 5)
+    ctx.set_option("split_wgs", split_wgs)
+    rng = np.random.default_rng(99)
+    n, m = 2700, 700                       # 22 tile rows: 253 tiles
+    geno = random_genotypes(rng, n, m, missing=0.03)
+    geno[n - 1], geno[1500] = geno[7], geno[130]
+    bits = oracle.bitset_from_genotypes(geno)
+    exp, _, _ = oracle.compute(oracle.submatrix(n), bits, 0.06, threads=16)
+    d_bits = ctx.upload_bitset(bits)
+    sm = cuking_amd.Submatrix(n)
+    try:
+        for swz in (0, 1):
+            for rows in (0, 1, 3, 5, 17, 64):
+                ctx.set_option("xcd_swizzle", swz)
+                ctx.set_option("band_rows", rows)
+                got = ctx.run(sm, bits.shape[1], d_bits, 0.06, max_results=1 << 20)
+                assert got.tobytes() == exp.tobytes(), (swz, rows)
+                tiles = ctx.num_tiles(sm)
+                parts = [ctx.run(sm, bits.shape[1], d_bits, 0.06, max_results=1 << 20,
+                                 tile_range=r, sort=False)
+                         for r in ((0, 100), (100, 101), (101, tiles))]
+                merged = cuking_amd.sort_results(np.concatenate(parts))
+                assert merged.tobytes() == exp.tobytes(), (swz, rows, "ranges")
+        # an off-diagonal block as well (no triangle in the enumeration)
+        ctx.set_option("xcd_swizzle", 1)
+        ctx.set_option("band_rows", 0)
+        off = cuking_amd.Submatrix(n, 2, 1)
+        idx = list(range(off.i_begin, off.i_end)) + list(range(off.j_begin, off.j_end))
+        sub = np.ascontiguousarray(bits[idx])
+        e2, _, _ = oracle.compute(oracle.submatrix(n, 2, 1), sub, 0.06, threads=16)
+        assert ctx.run(off, bits.shape[1], ctx.upload_bitset(sub), 0.06,
+                       max_results=1 << 20).tobytes() == e2.tobytes()
+    finally:
+        ctx.set_option("xcd_swizzle", 1)
+        ctx.set_option("band_rows", 0)
+        ctx.set_option("split_wgs", 256)
