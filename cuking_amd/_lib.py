@@ -52,6 +52,8 @@ SIGNATURES = {
     "cuking_words_per_sample": (_u32, [_u32]),
     "cuking_bytes_per_pair": (_u64, [_u32]),
     "cuking_pack_host": (_int, [_SM, _u32, _vp, _vp, _vp, _vp, _sz]),
+    "cuking_narrow_triples": (_int, [_SM, _u32, _vp, _vp, _vp, _sz, _vp, _vp,
+                                     C.POINTER(_sz)]),
     "cuking_last_error": (C.c_char_p, []),
     "cuking_abi_version": (_u32, []),
     "cuking_device_count": (_int, []),
@@ -65,10 +67,16 @@ SIGNATURES = {
     "cuking_stream_synchronize": (_int, [_vp, _vp]),
     "cuking_stream_create": (_int, [_vp, C.POINTER(_vp)]),
     "cuking_stream_destroy": (_int, [_vp, _vp]),
+    "cuking_event_create": (_int, [_vp, C.POINTER(_vp)]),
+    "cuking_event_record": (_int, [_vp, _vp, _vp]),
+    "cuking_event_synchronize": (_int, [_vp, _vp]),
+    "cuking_event_destroy": (_int, [_vp, _vp]),
     "cuking_host_alloc": (_int, [_vp, _sz, C.POINTER(_vp)]),
     "cuking_host_free": (_int, [_vp, _vp]),
     "cuking_pack_device": (_int, [_vp, _SM, _u32, _vp, _vp, _vp, _vp, _sz,
                                   _vp, _vp]),
+    "cuking_pack_device_compact": (_int, [_vp, _SM, _u32, _vp, _vp, _vp, _sz, _vp,
+                                          _vp]),
     "cuking_ctx_set_kernel": (_int, [_vp, _int]),
     "cuking_ctx_set_option": (_int, [_vp, C.c_char_p, _i64]),
     "cuking_ctx_get_option": (_int, [_vp, C.c_char_p, C.POINTER(_i64)]),

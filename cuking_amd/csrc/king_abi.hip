@@ -627,6 +627,39 @@ cuking_status cuking_pack_host(const cuking_submatrix *sm,
   return CUKING_OK;
 }
 
+cuking_status cuking_narrow_triples(const cuking_submatrix *sm, uint32_t words_per_sample,
+                                    const int64_t *row_idx, const int64_t *col_idx,
+                                    const int32_t *n_alt_alleles, size_t num_triples,
+                                    uint32_t *site, uint32_t *sample_alt,
+                                    size_t *num_out) {
+  cuking_status st = check_block(sm, words_per_sample);
+  if (st != CUKING_OK) return st;
+  if (num_out == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null out pointer");
+  *num_out = 0;
+  if (cuking_submatrix_num_samples(sm) > 0x3FFFFFFFu)
+    return fail(CUKING_ERR_INVALID_ARGUMENT, "block holds more than 2^30 samples");
+  const uint64_t plane_bits = (uint64_t)(words_per_sample / 2) * 64;
+  size_t w = 0;
+  for (size_t t = 0; t < num_triples; ++t) {
+    const int64_t col = col_idx[t];
+    if (col < 0 || col > 0xFFFFFFFFll || !sm_contains(*sm, (uint32_t)col)) continue;
+    const int64_t row = row_idx[t];
+    if (row < 0 || (uint64_t)row >= plane_bits)
+      return fail(CUKING_ERR_INVALID_ARGUMENT,
+                  "row_idx %lld outside the %llu padded sites", (long long)row,
+                  (unsigned long long)plane_bits);
+    const int32_t g = n_alt_alleles[t];
+    if (g < 0 || g > 2)
+      return fail(CUKING_ERR_FAILED_PRECONDITION,
+                  "Invalid value for n_alt_alleles (%d) encountered", g);
+    site[w] = (uint32_t)row;
+    sample_alt[w] = sm_sample_offset(*sm, (uint32_t)col) | ((uint32_t)g << 30);
+    ++w;
+  }
+  *num_out = w;
+  return CUKING_OK;
+}
+
 void cuking_sort_results(cuking_result *results, size_t num_results) {
   std::sort(results, results + num_results,
             [](const cuking_result &a, const cuking_result &b) {
@@ -865,6 +898,53 @@ cuking_status cuking_pack_device(cuking_ctx *ctx, const cuking_submatrix *sm,
   HIP_TRY(launch_pack(*sm, words_per_sample, d_bit_set, d_row_idx, d_col_idx,
                       d_n_alt_alleles, num_triples, d_status,
                       (hipStream_t)stream));
+  return CUKING_OK;
+}
+
+cuking_status cuking_pack_device_compact(cuking_ctx *ctx, const cuking_submatrix *sm,
+                                         uint32_t words_per_sample, uint64_t *d_bit_set,
+                                         const uint32_t *d_site,
+                                         const uint32_t *d_sample_alt, size_t num_triples,
+                                         uint32_t *d_status, void *stream) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  st = check_block(sm, words_per_sample);
+  if (st != CUKING_OK) return st;
+  if (num_triples && (!d_bit_set || !d_site || !d_sample_alt || !d_status))
+    return fail(CUKING_ERR_INVALID_ARGUMENT, "null device pointer");
+  HIP_TRY(launch_pack_compact(words_per_sample, sm_num_samples(*sm), d_bit_set, d_site,
+                              d_sample_alt, num_triples, d_status, (hipStream_t)stream));
+  return CUKING_OK;
+}
+
+cuking_status cuking_event_create(cuking_ctx *ctx, void **event) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  if (event == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null out pointer");
+  hipEvent_t e = nullptr;
+  HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  *event = e;
+  return CUKING_OK;
+}
+
+cuking_status cuking_event_record(cuking_ctx *ctx, void *event, void *stream) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  HIP_TRY(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+  return CUKING_OK;
+}
+
+cuking_status cuking_event_synchronize(cuking_ctx *ctx, void *event) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  HIP_TRY(hipEventSynchronize((hipEvent_t)event));
+  return CUKING_OK;
+}
+
+cuking_status cuking_event_destroy(cuking_ctx *ctx, void *event) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  if (event) HIP_TRY(hipEventDestroy((hipEvent_t)event));
   return CUKING_OK;
 }
 

@@ -210,6 +210,11 @@ hipError_t launch_pack(const cuking_submatrix &sm, uint32_t words_per_sample,
                        size_t num_triples, uint32_t *d_status,
                        hipStream_t stream);
 
+hipError_t launch_pack_compact(uint32_t words_per_sample, uint32_t num_samples,
+                               uint64_t *d_bit_set, const uint32_t *d_site,
+                               const uint32_t *d_sample_alt, size_t num_triples,
+                               uint32_t *d_status, hipStream_t stream);
+
 hipError_t launch_synth(uint64_t seed, const uint32_t *d_kind,
                         const uint32_t *d_pa, const uint32_t *d_pb,
                         uint32_t sample_begin, uint32_t sample_end,

@@ -515,6 +515,43 @@ __global__ __launch_bounds__(256) void pack_kernel(
   if (bad) atomicOr(status, bad);
 }
 
+// The same for triples a host has already filtered to the block and narrowed:
+// site index, and block-local sample offset (bits 0..29) with the allele count
+// in bits 30..31 -- 8 bytes per genotype on the wire instead of 20.
+__global__ __launch_bounds__(256) void pack_compact_kernel(
+    const uint32_t words_per_sample, const uint32_t num_samples, uint64_t *bit_set,
+    const uint32_t *__restrict__ site, const uint32_t *__restrict__ sample_alt,
+    const uint64_t num_triples, uint32_t *status) {
+  const uint32_t plane_words = words_per_sample / 2;
+  const uint64_t plane_bits = (uint64_t)plane_words * 64;
+  uint32_t bad = 0;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       t < num_triples; t += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t sa = sample_alt[t], row = site[t];
+    const uint32_t sample = sa & 0x3FFFFFFFu, g = sa >> 30;
+    if (row >= plane_bits || sample >= num_samples) {
+      bad |= 2u;
+      continue;
+    }
+    unsigned long long *het = reinterpret_cast<unsigned long long *>(
+        bit_set + (uint64_t)sample * words_per_sample);
+    unsigned long long *hom = het + plane_words;
+    const unsigned long long clear = ~(1ull << (row & 63));
+    const uint32_t word = row >> 6;
+    if (g == 0) {
+      atomicAnd(het + word, clear);
+      atomicAnd(hom + word, clear);
+    } else if (g == 1) {
+      atomicAnd(hom + word, clear);
+    } else if (g == 2) {
+      atomicAnd(het + word, clear);
+    } else {
+      bad |= 1u;
+    }
+  }
+  if (bad) atomicOr(status, bad);
+}
+
 uint64_t g_max_blocks_override = 0;  // tests: force splitting at small sizes
 
 template <int TIT, int TJT, int RI, int RJ, int KC, int KU, int MINW, bool FULL,
@@ -661,6 +698,18 @@ hipError_t launch_pack(const cuking_submatrix &sm, uint32_t words_per_sample,
   pack_kernel<<<dim3((uint32_t)blocks), dim3(256), 0, stream>>>(
       sm, words_per_sample, d_bit_set, d_row_idx, d_col_idx, d_n_alt,
       num_triples, d_status);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_compact(uint32_t words_per_sample, uint32_t num_samples,
+                               uint64_t *d_bit_set, const uint32_t *d_site,
+                               const uint32_t *d_sample_alt, size_t num_triples,
+                               uint32_t *d_status, hipStream_t stream) {
+  if (num_triples == 0) return hipSuccess;
+  uint64_t blocks = (num_triples + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride the rest
+  pack_compact_kernel<<<dim3((uint32_t)blocks), dim3(256), 0, stream>>>(
+      words_per_sample, num_samples, d_bit_set, d_site, d_sample_alt, num_triples, d_status);
   return hipGetLastError();
 }
 

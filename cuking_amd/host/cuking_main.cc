@@ -149,57 +149,76 @@ struct DeviceBuffers {
   }
 };
 
-// --pack=device: one per reader thread.  Triples of a decoded table are copied
-// into page-locked staging (two buffers, alternating), sent to the GPU and
-// packed by pack_kernel on the thread's own stream, so the next table is being
-// decoded (and the next chunk staged) while the previous one is in flight.
+// --pack=device: one per reader thread.  A decoded table goes to the GPU in
+// pieces of kChunkTriples through a ring of kSlots page-locked buffers: each
+// piece is filtered to the shard and narrowed to 8 bytes per genotype on the
+// host (cuking_narrow_triples; the reference's own validation, cuking.cu:677-702,
+// happens there), copied asynchronously and packed by pack_compact_kernel on
+// the thread's own stream.  Before a slot is refilled the thread waits for THAT
+// slot's previous piece only (an event), so the host fills piece n + 2 while
+// pieces n and n + 1 are on the wire or in the kernel, and the next table is
+// being decoded while the tail of this one is still in flight.
 class DevicePacker {
  public:
-  static constexpr size_t kChunkTriples = size_t(2) << 20;  // 40 MiB per buffer
-  static constexpr size_t kBytesPerTriple = 8 + 8 + 4;
+  static constexpr size_t kChunkTriples = size_t(256) << 10;  // 2 MiB per slot
+  static constexpr int kSlots = 3;
 
   explicit DevicePacker(cuking_ctx *ctx) : ctx_(ctx) {}
   ~DevicePacker() {
     if (stream_) cuking_stream_synchronize(ctx_, stream_);
-    for (int b = 0; b < 2; ++b) {
-      if (host_[b]) cuking_host_free(ctx_, host_[b]);
-      if (dev_[b]) cuking_device_free(ctx_, dev_[b]);
-    }
+    for (int b = 0; b < kSlots; ++b)
+      if (event_[b]) cuking_event_destroy(ctx_, event_[b]);
+    if (host_) cuking_host_free(ctx_, host_);
+    if (dev_) cuking_device_free(ctx_, dev_);
     if (stream_) cuking_stream_destroy(ctx_, stream_);
   }
 
-  // Returns "" or the ABI error message.
+  // Returns "" or "<CODE>\n<message>".
   std::string Pack(const cuking_submatrix &sm, uint32_t words_per_sample,
                    uint64_t *d_bits, const cuking_host::Triples &t,
                    uint32_t *d_status) {
-    if (!stream_ && cuking_stream_create(ctx_, &stream_) != CUKING_OK)
-      return cuking_last_error();
+    auto abi_error = [](cuking_status st) {
+      const char *code = st == CUKING_ERR_FAILED_PRECONDITION ? "FAILED_PRECONDITION"
+                         : st == CUKING_ERR_INVALID_ARGUMENT  ? "INVALID_ARGUMENT"
+                                                              : "INTERNAL";
+      return std::string(code) + "\n" + cuking_last_error();
+    };
+    if (!stream_) {
+      // one allocation each for the whole ring (page-locking is the slow part)
+      cuking_status st = cuking_stream_create(ctx_, &stream_);
+      if (st == CUKING_OK) st = cuking_host_alloc(ctx_, kSlots * kSlotBytes, &host_);
+      if (st == CUKING_OK) st = cuking_device_alloc(ctx_, kSlots * kSlotBytes, &dev_);
+      for (int b = 0; b < kSlots && st == CUKING_OK; ++b)
+        st = cuking_event_create(ctx_, &event_[b]);
+      if (st != CUKING_OK) return abi_error(st);
+    }
     const size_t n = t.row_idx.size();
     for (size_t done = 0; done < n; done += kChunkTriples) {
       const size_t m = std::min(kChunkTriples, n - done);
       const int b = next_;
-      next_ ^= 1;
-      if (!host_[b]) {
-        if (cuking_host_alloc(ctx_, kChunkTriples * kBytesPerTriple, &host_[b]) != CUKING_OK ||
-            cuking_device_alloc(ctx_, kChunkTriples * kBytesPerTriple, &dev_[b]) != CUKING_OK)
-          return cuking_last_error();
-      } else if (cuking_stream_synchronize(ctx_, stream_) != CUKING_OK) {
-        // (the buffer's previous chunk must have left the staging area; the
-        //  stream is in order, so this also covers the other buffer)
-        return cuking_last_error();
+      next_ = (next_ + 1) % kSlots;
+      if (used_[b]) {
+        const cuking_status st = cuking_event_synchronize(ctx_, event_[b]);
+        if (st != CUKING_OK) return abi_error(st);
       }
-      char *h = static_cast<char *>(host_[b]);
-      memcpy(h, t.row_idx.data() + done, m * 8);
-      memcpy(h + m * 8, t.col_idx.data() + done, m * 8);
-      memcpy(h + m * 16, t.n_alt_alleles.data() + done, m * 4);
-      char *d = static_cast<char *>(dev_[b]);
-      if (cuking_copy_to_device(ctx_, d, h, m * kBytesPerTriple, stream_) != CUKING_OK ||
-          cuking_pack_device(ctx_, &sm, words_per_sample, d_bits,
-                             reinterpret_cast<int64_t *>(d),
-                             reinterpret_cast<int64_t *>(d + m * 8),
-                             reinterpret_cast<int32_t *>(d + m * 16), m, d_status,
-                             stream_) != CUKING_OK)
-        return cuking_last_error();
+      uint32_t *h_site = reinterpret_cast<uint32_t *>(static_cast<char *>(host_) + b * kSlotBytes);
+      uint32_t *h_sa = h_site + kChunkTriples;
+      size_t kept = 0;
+      cuking_status st = cuking_narrow_triples(
+          &sm, words_per_sample, t.row_idx.data() + done, t.col_idx.data() + done,
+          t.n_alt_alleles.data() + done, m, h_site, h_sa, &kept);
+      if (st != CUKING_OK) return abi_error(st);
+      if (kept == 0) continue;
+      uint32_t *d_site = reinterpret_cast<uint32_t *>(static_cast<char *>(dev_) + b * kSlotBytes);
+      uint32_t *d_sa = d_site + kChunkTriples;
+      st = cuking_copy_to_device(ctx_, d_site, h_site, kept * 4, stream_);
+      if (st == CUKING_OK) st = cuking_copy_to_device(ctx_, d_sa, h_sa, kept * 4, stream_);
+      if (st == CUKING_OK)
+        st = cuking_pack_device_compact(ctx_, &sm, words_per_sample, d_bits, d_site, d_sa, kept,
+                                        d_status, stream_);
+      if (st == CUKING_OK) st = cuking_event_record(ctx_, event_[b], stream_);
+      if (st != CUKING_OK) return abi_error(st);
+      used_[b] = true;
     }
     return "";
   }
@@ -211,10 +230,12 @@ class DevicePacker {
   }
 
  private:
+  static constexpr size_t kSlotBytes = kChunkTriples * 8;
   cuking_ctx *ctx_;
   void *stream_ = nullptr;
-  void *host_[2] = {nullptr, nullptr};
-  void *dev_[2] = {nullptr, nullptr};
+  void *host_ = nullptr, *dev_ = nullptr;
+  void *event_[kSlots] = {nullptr, nullptr, nullptr};
+  bool used_[kSlots] = {false, false, false};
   int next_ = 0;
 };
 
@@ -376,7 +397,7 @@ Status Run(const Flags &flags) {
           const std::string msg =
               packer->Pack(sm, words_per_sample, static_cast<uint64_t *>(buf.d_bits), t,
                            d_pack_status);
-          if (!msg.empty()) return "INTERNAL\n" + msg;
+          if (!msg.empty()) return msg + " in " + input_files[f].first;
         }
         pack_us += now_us() - t_decoded;
         num_triples += n;
@@ -420,7 +441,11 @@ Status Run(const Flags &flags) {
     cuking_host_free(buf.ctx, buf.host_bits);
     buf.host_bits = nullptr;
   }
-  Done(&sw);
+  // (list -> decode -> pack -> bitset on the GPU; with --num_gpus and host pack
+  //  the upload belongs to the broadcast that follows)
+  const double read_pack_seconds = sw.ElapsedAndReset();
+  std::cout << " (" << std::fixed << std::setprecision(3) << read_pack_seconds << "s)"
+            << std::endl;
 
   const uint32_t num_rows = cuking_submatrix_num_rows(&sm);
   const uint32_t num_cols = cuking_submatrix_num_cols(&sm);
@@ -534,6 +559,11 @@ Status Run(const Flags &flags) {
             << ", \"results\": " << num_results << ", \"decode_thread_seconds\": "
             << std::setprecision(3) << decode_us.load() * 1e-6
             << ", \"pack_thread_seconds\": " << pack_us.load() * 1e-6
+            << ", \"pack\": \"" << flags.pack << "\", \"reader_threads\": "
+            << flags.num_reader_threads << ", \"read_pack_seconds\": " << read_pack_seconds
+            << ", \"triples_per_second\": " << std::setprecision(1)
+            << (read_pack_seconds > 0 ? num_triples.load() / read_pack_seconds : 0.0)
+            << std::setprecision(3)
             << ", \"kernel_seconds\": "
             << std::setprecision(6) << kernel_seconds << ", \"pairs_per_second\": "
             << std::setprecision(1) << rate << ", \"algorithmic_GBps\": "

@@ -92,6 +92,20 @@ cuking_status cuking_pack_host(const cuking_submatrix *sm,
                                const int32_t *n_alt_alleles,
                                size_t num_triples);
 
+/* Host half of the compact device pack (below): filters triples to the block
+ * (cuking.cu:677-679), validates them exactly like cuking_pack_host (same
+ * status codes and messages) and writes, for each one kept, its site index and
+ * its block-local sample offset (cuking.cu:171-175) with n_alt in bits 30..31:
+ * 8 bytes per genotype for the trip to the GPU instead of the 20 of the three
+ * Parquet columns.  site / sample_alt hold num_triples entries; *num_out =
+ * entries written.  Thread-safe (no shared state). */
+cuking_status cuking_narrow_triples(const cuking_submatrix *sm,
+                                    uint32_t words_per_sample,
+                                    const int64_t *row_idx, const int64_t *col_idx,
+                                    const int32_t *n_alt_alleles, size_t num_triples,
+                                    uint32_t *site, uint32_t *sample_alt,
+                                    size_t *num_out);
+
 /* Message of the calling thread's most recent failing call ("" if none). */
 const char *cuking_last_error(void);
 uint32_t cuking_abi_version(void);
@@ -123,6 +137,12 @@ cuking_status cuking_stream_synchronize(cuking_ctx *ctx, void *stream);
  * compute / prepare / timing entry points need one caller at a time. */
 cuking_status cuking_stream_create(cuking_ctx *ctx, void **stream);
 cuking_status cuking_stream_destroy(cuking_ctx *ctx, void *stream);
+/* Events, for hosts that pipeline several staging buffers through one stream
+ * (wait for ONE earlier piece of work instead of the whole stream). */
+cuking_status cuking_event_create(cuking_ctx *ctx, void **event);
+cuking_status cuking_event_record(cuking_ctx *ctx, void *event, void *stream);
+cuking_status cuking_event_synchronize(cuking_ctx *ctx, void *event);
+cuking_status cuking_event_destroy(cuking_ctx *ctx, void *event);
 /* Page-locked host memory for staging buffers. */
 cuking_status cuking_host_alloc(cuking_ctx *ctx, size_t bytes, void **ptr);
 cuking_status cuking_host_free(cuking_ctx *ctx, void *ptr);
@@ -142,6 +162,16 @@ cuking_status cuking_pack_device(cuking_ctx *ctx, const cuking_submatrix *sm,
                                  const int32_t *d_n_alt_alleles,
                                  size_t num_triples, uint32_t *d_status,
                                  void *stream);
+
+/* The same for triples prepared by cuking_narrow_triples (device copies of its
+ * two output arrays).  *d_status as above (2 also flags a sample offset outside
+ * the block). */
+cuking_status cuking_pack_device_compact(cuking_ctx *ctx, const cuking_submatrix *sm,
+                                         uint32_t words_per_sample,
+                                         uint64_t *d_bit_set, const uint32_t *d_site,
+                                         const uint32_t *d_sample_alt,
+                                         size_t num_triples, uint32_t *d_status,
+                                         void *stream);
 
 /* Which device kernel evaluates the pairs. */
 typedef enum cuking_kernel {

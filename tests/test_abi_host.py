@@ -202,3 +202,60 @@ def test_no_cpu_fallback_without_gpu():
         cuking_amd.KingContext(0)
     assert e.value.status == _lib.ERR_DEVICE
     assert "no CPU path" in e.value.message
+
+
+def test_narrow_triples_matches_pack_host(oracle):
+    """cuking_narrow_triples (host half of the compact device pack): the kept
+    entries, replayed bit by bit, give the bitset cuking_pack_host builds; same
+    filter (cuking.cu:677-679) and the same errors (:698-702)."""
+    import ctypes as C
+    from cuking_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    n, m = 37, 210
+    geno = random_genotypes(rng, n, m, missing=0.1)
+    col, row = np.nonzero(geno >= 0)
+    alt = geno[col, row].astype(np.int32)
+    perm = rng.permutation(len(row))
+    row, col, alt = (np.ascontiguousarray(a[perm]) for a in (row.astype(np.int64),
+                                                             col.astype(np.int64), alt))
+    for k, shard in ((1, 0), (3, 1), (3, 3)):
+        sm = cuking_amd.Submatrix(n, k, shard)
+        want = cuking_amd.new_host_bitset(sm, m)
+        cuking_amd.pack_host(sm, want, row, col, alt)
+        site = np.zeros(len(row), dtype=np.uint32)
+        sa = np.zeros(len(row), dtype=np.uint32)
+        kept = C.c_size_t(0)
+        _lib.check(lib.cuking_narrow_triples(C.byref(sm.c), want.shape[1], row.ctypes.data,
+                                             col.ctypes.data, alt.ctypes.data, len(row),
+                                             site.ctypes.data, sa.ctypes.data, C.byref(kept)))
+        inside = np.array([sm.Contains(int(c)) for c in col])
+        assert kept.value == int(inside.sum())
+        got = cuking_amd.new_host_bitset(sm, m)
+        plane = want.shape[1] // 2
+        for s_, x in zip(site[:kept.value].tolist(), sa[:kept.value].tolist()):
+            sample, g = x & 0x3FFFFFFF, x >> 30
+            bit = ~np.uint64(1 << (s_ & 63))
+            if g in (0, 2):
+                got[sample, s_ >> 6] &= bit
+            if g in (0, 1):
+                got[sample, plane + (s_ >> 6)] &= bit
+        assert np.array_equal(got, want)
+    sm = cuking_amd.Submatrix(n)
+    wps = cuking_amd.words_per_sample(m)
+    kept = C.c_size_t(0)
+    buf = np.zeros(4, dtype=np.uint32)
+    one = lambda r, c, a: (np.array([r], np.int64), np.array([c], np.int64), np.array([a], np.int32))
+    r_, c_, a_ = one(0, 1, 3)
+    assert lib.cuking_narrow_triples(C.byref(sm.c), wps, r_.ctypes.data, c_.ctypes.data,
+                                     a_.ctypes.data, 1, buf.ctypes.data, buf[2:].ctypes.data,
+                                     C.byref(kept)) == _lib.ERR_FAILED_PRECONDITION
+    assert b"Invalid value for n_alt_alleles (3)" in lib.cuking_last_error()
+    r_, c_, a_ = one(10 ** 6, 1, 1)
+    assert lib.cuking_narrow_triples(C.byref(sm.c), wps, r_.ctypes.data, c_.ctypes.data,
+                                     a_.ctypes.data, 1, buf.ctypes.data, buf[2:].ctypes.data,
+                                     C.byref(kept)) == _lib.ERR_INVALID_ARGUMENT
+    r_, c_, a_ = one(5, n + 4, 7)          # outside the block: skipped before validation
+    assert lib.cuking_narrow_triples(C.byref(sm.c), wps, r_.ctypes.data, c_.ctypes.data,
+                                     a_.ctypes.data, 1, buf.ctypes.data, buf[2:].ctypes.data,
+                                     C.byref(kept)) == 0 and kept.value == 0
