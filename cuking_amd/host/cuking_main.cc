@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <future>
 #include <cstdio>
 #include <cstring>
 #include <iomanip>
@@ -22,6 +23,7 @@
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "cuking_amd.h"
@@ -139,8 +141,11 @@ struct DeviceBuffers {
   cuking_ctx *ctx = nullptr;
   void *host_bits = nullptr;
   void *d_bits = nullptr, *d_results = nullptr, *d_counters = nullptr;
+  void *pack_host = nullptr, *pack_dev = nullptr;  // --pack=device staging rings
   ~DeviceBuffers() {
     if (ctx == nullptr) return;
+    if (pack_host) cuking_host_free(ctx, pack_host);
+    if (pack_dev) cuking_device_free(ctx, pack_dev);
     if (host_bits) cuking_host_free(ctx, host_bits);
     if (d_bits) cuking_device_free(ctx, d_bits);
     if (d_results) cuking_device_free(ctx, d_results);
@@ -158,19 +163,36 @@ struct DeviceBuffers {
 // slot's previous piece only (an event), so the host fills piece n + 2 while
 // pieces n and n + 1 are on the wire or in the kernel, and the next table is
 // being decoded while the tail of this one is still in flight.
+// Where the reader threads' device-pack time goes (summed over threads).
+struct PackerStats {
+  std::atomic<uint64_t> setup_us{0}, wait_us{0}, narrow_us{0}, enqueue_us{0};
+};
+
 class DevicePacker {
  public:
-  static constexpr size_t kChunkTriples = size_t(256) << 10;  // 2 MiB per slot
+  static constexpr size_t kChunkTriples = size_t(512) << 10;  // 4 MiB per slot
   static constexpr int kSlots = 3;
+  static constexpr size_t kSlotBytes = kChunkTriples * 8;
+  static constexpr size_t kRingBytes = kSlots * kSlotBytes;
+  PackerStats *stats = nullptr;
 
-  explicit DevicePacker(cuking_ctx *ctx) : ctx_(ctx) {}
+  // `host` / `dev`: this packer's kRingBytes of page-locked and of device
+  // memory, carved out of ONE allocation each by the caller: 64 reader threads
+  // each pinning their own ring spent 0.65 s apiece inside the driver's locks.
+  DevicePacker(cuking_ctx *ctx, void *host, void *dev) : ctx_(ctx), host_(host), dev_(dev) {}
   ~DevicePacker() {
     if (stream_) cuking_stream_synchronize(ctx_, stream_);
     for (int b = 0; b < kSlots; ++b)
       if (event_[b]) cuking_event_destroy(ctx_, event_[b]);
-    if (host_) cuking_host_free(ctx_, host_);
-    if (dev_) cuking_device_free(ctx_, dev_);
     if (stream_) cuking_stream_destroy(ctx_, stream_);
+  }
+
+  // Stream and events (main thread, before the readers start).
+  std::string Init() {
+    cuking_status st = cuking_stream_create(ctx_, &stream_);
+    for (int b = 0; b < kSlots && st == CUKING_OK; ++b)
+      st = cuking_event_create(ctx_, &event_[b]);
+    return st == CUKING_OK ? "" : cuking_last_error();
   }
 
   // Returns "" or "<CODE>\n<message>".
@@ -183,42 +205,42 @@ class DevicePacker {
                                                               : "INTERNAL";
       return std::string(code) + "\n" + cuking_last_error();
     };
-    if (!stream_) {
-      // one allocation each for the whole ring (page-locking is the slow part)
-      cuking_status st = cuking_stream_create(ctx_, &stream_);
-      if (st == CUKING_OK) st = cuking_host_alloc(ctx_, kSlots * kSlotBytes, &host_);
-      if (st == CUKING_OK) st = cuking_device_alloc(ctx_, kSlots * kSlotBytes, &dev_);
-      for (int b = 0; b < kSlots && st == CUKING_OK; ++b)
-        st = cuking_event_create(ctx_, &event_[b]);
-      if (st != CUKING_OK) return abi_error(st);
-    }
+    auto now = []() {
+      return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(
+                 std::chrono::steady_clock::now().time_since_epoch()).count();
+    };
     const size_t n = t.row_idx.size();
     for (size_t done = 0; done < n; done += kChunkTriples) {
       const size_t m = std::min(kChunkTriples, n - done);
       const int b = next_;
       next_ = (next_ + 1) % kSlots;
+      uint64_t t0 = now();
       if (used_[b]) {
         const cuking_status st = cuking_event_synchronize(ctx_, event_[b]);
         if (st != CUKING_OK) return abi_error(st);
       }
+      uint64_t t1 = now();
+      if (stats) stats->wait_us += t1 - t0;
+      // [site x m][sample_alt x m]: one contiguous piece, one copy
       uint32_t *h_site = reinterpret_cast<uint32_t *>(static_cast<char *>(host_) + b * kSlotBytes);
-      uint32_t *h_sa = h_site + kChunkTriples;
+      uint32_t *h_sa = h_site + m;
       size_t kept = 0;
       cuking_status st = cuking_narrow_triples(
           &sm, words_per_sample, t.row_idx.data() + done, t.col_idx.data() + done,
           t.n_alt_alleles.data() + done, m, h_site, h_sa, &kept);
       if (st != CUKING_OK) return abi_error(st);
+      t0 = now();
+      if (stats) stats->narrow_us += t0 - t1;
       if (kept == 0) continue;
       uint32_t *d_site = reinterpret_cast<uint32_t *>(static_cast<char *>(dev_) + b * kSlotBytes);
-      uint32_t *d_sa = d_site + kChunkTriples;
-      st = cuking_copy_to_device(ctx_, d_site, h_site, kept * 4, stream_);
-      if (st == CUKING_OK) st = cuking_copy_to_device(ctx_, d_sa, h_sa, kept * 4, stream_);
+      st = cuking_copy_to_device(ctx_, d_site, h_site, (m + kept) * 4, stream_);
       if (st == CUKING_OK)
-        st = cuking_pack_device_compact(ctx_, &sm, words_per_sample, d_bits, d_site, d_sa, kept,
-                                        d_status, stream_);
+        st = cuking_pack_device_compact(ctx_, &sm, words_per_sample, d_bits, d_site, d_site + m,
+                                        kept, d_status, stream_);
       if (st == CUKING_OK) st = cuking_event_record(ctx_, event_[b], stream_);
       if (st != CUKING_OK) return abi_error(st);
       used_[b] = true;
+      if (stats) stats->enqueue_us += now() - t0;
     }
     return "";
   }
@@ -230,7 +252,6 @@ class DevicePacker {
   }
 
  private:
-  static constexpr size_t kSlotBytes = kChunkTriples * 8;
   cuking_ctx *ctx_;
   void *stream_ = nullptr;
   void *host_ = nullptr, *dev_ = nullptr;
@@ -359,19 +380,58 @@ Status Run(const Flags &flags) {
     return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(
                std::chrono::steady_clock::now().time_since_epoch()).count();
   };
-  std::mutex device_mu;
+  PackerStats packer_stats;
   std::vector<std::unique_ptr<DevicePacker>> packers;
   uint32_t *d_pack_status = nullptr;
+  std::atomic<size_t> next_packer(0);
   if (pack_on_device) {
     RETURN_IF_ERROR(FromAbi(cuking_device_alloc(buf.ctx, sizeof(uint32_t),
                                                 reinterpret_cast<void **>(&d_pack_status))));
     RETURN_IF_ERROR(FromAbi(
         cuking_memset_async(buf.ctx, d_pack_status, 0, sizeof(uint32_t), nullptr)));
-    // The packers' streams are non-blocking, i.e. NOT ordered behind the null
-    // stream: the all-ones fill of the bitset (tens of ms at cohort scale) and
-    // the zeroed status word must be complete before the first pack kernel.
-    RETURN_IF_ERROR(FromAbi(cuking_stream_synchronize(buf.ctx, nullptr)));
   }
+  // One staging ring per reader thread that can be busy at once, carved out of
+  // one page-locked and one device allocation -- made on a helper thread while
+  // the readers already decode their first tables (page-locking 100-200 MB
+  // takes about as long as decoding one table); a reader waits for it before
+  // its first piece.
+  std::string setup_error;
+  std::thread setup_thread;
+  std::shared_future<void> setup_done;
+  if (pack_on_device) {
+    std::promise<void> promise;
+    setup_done = promise.get_future().share();
+    setup_thread = std::thread([&, promise = std::move(promise)]() mutable {
+      const size_t rings = std::min(flags.num_reader_threads, input_files.size());
+      const uint64_t setup_begin = now_us();
+      auto check = [&](cuking_status st) {
+        if (st != CUKING_OK && setup_error.empty()) setup_error = cuking_last_error();
+        return st == CUKING_OK;
+      };
+      if (check(cuking_host_alloc(buf.ctx, rings * DevicePacker::kRingBytes, &buf.pack_host)) &&
+          check(cuking_device_alloc(buf.ctx, rings * DevicePacker::kRingBytes, &buf.pack_dev))) {
+        for (size_t r = 0; r < rings && setup_error.empty(); ++r) {
+          packers.emplace_back(new DevicePacker(
+              buf.ctx, static_cast<char *>(buf.pack_host) + r * DevicePacker::kRingBytes,
+              static_cast<char *>(buf.pack_dev) + r * DevicePacker::kRingBytes));
+          packers.back()->stats = &packer_stats;
+          setup_error = packers.back()->Init();
+        }
+      }
+      // The packers' streams are non-blocking, i.e. NOT ordered behind the null
+      // stream: the all-ones fill of the bitset (tens of ms at cohort scale) and
+      // the zeroed status word must be complete before the first pack kernel.
+      check(cuking_stream_synchronize(buf.ctx, nullptr));
+      packer_stats.setup_us += now_us() - setup_begin;
+      promise.set_value();
+    });
+  }
+  struct Joiner {  // (every exit path below joins the helper)
+    std::thread &t;
+    ~Joiner() {
+      if (t.joinable()) t.join();
+    }
+  } joiner{setup_thread};
   const std::string pack_error = cuking_host::ParallelFor(
       flags.num_reader_threads, 0, input_files.size(), [&](size_t f) -> std::string {
         cuking_host::Triples t;
@@ -387,12 +447,12 @@ Status Run(const Flags &flags) {
             return std::string("FAILED_PRECONDITION\n") + cuking_last_error() + " in " +
                    input_files[f].first;
         } else if (n > 0) {
-          // One packer (stream + staging) per reader thread.
+          // One packer (stream + staging ring) per reader thread.
           thread_local DevicePacker *packer = nullptr;
           if (packer == nullptr) {
-            std::lock_guard<std::mutex> lock(device_mu);
-            packers.emplace_back(new DevicePacker(buf.ctx));
-            packer = packers.back().get();
+            setup_done.wait();
+            if (!setup_error.empty()) return "INTERNAL\n" + setup_error;
+            packer = packers[next_packer.fetch_add(1) % packers.size()].get();
           }
           const std::string msg =
               packer->Pack(sm, words_per_sample, static_cast<uint64_t *>(buf.d_bits), t,
@@ -559,6 +619,11 @@ Status Run(const Flags &flags) {
             << ", \"results\": " << num_results << ", \"decode_thread_seconds\": "
             << std::setprecision(3) << decode_us.load() * 1e-6
             << ", \"pack_thread_seconds\": " << pack_us.load() * 1e-6
+            << ", \"device_pack_thread_seconds\": {\"setup\": "
+            << packer_stats.setup_us.load() * 1e-6 << ", \"slot_wait\": "
+            << packer_stats.wait_us.load() * 1e-6 << ", \"narrow\": "
+            << packer_stats.narrow_us.load() * 1e-6 << ", \"enqueue\": "
+            << packer_stats.enqueue_us.load() * 1e-6 << "}"
             << ", \"pack\": \"" << flags.pack << "\", \"reader_threads\": "
             << flags.num_reader_threads << ", \"read_pack_seconds\": " << read_pack_seconds
             << ", \"triples_per_second\": " << std::setprecision(1)

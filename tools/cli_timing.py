@@ -96,13 +96,15 @@ def main():
                    "triples_per_second": summary["triples_per_second"],
                    "decode_thread_seconds": summary["decode_thread_seconds"],
                    "pack_thread_seconds": summary["pack_thread_seconds"],
+                   "device_pack_thread_seconds": summary.get("device_pack_thread_seconds"),
                    "kernel_seconds": summary["kernel_seconds"], "results": summary["results"]}
             report["runs"].append(run)
             print(f"rep {rep} pack={pack:6s} wall {wall:6.2f}s  read+pack "
                   f"{run['read_pack_seconds']:.3f}s = {run['triples_per_second']:.3e} triples/s  "
                   f"(decode {run['decode_thread_seconds']:.2f} / pack "
                   f"{run['pack_thread_seconds']:.2f} thread-s)  kernel {run['kernel_seconds']:.3f}s  "
-                  f"{run['results']} records", flush=True)
+                  f"{run['results']} records  {run['device_pack_thread_seconds'] if pack == 'device' else ''}",
+                  flush=True)
     if a.out:
         with open(a.out, "a") as f:
             f.write(json.dumps(report) + "\n")
