@@ -353,6 +353,12 @@ def single_gpu_workload(args, ctx, n, m, thr, steps, warmup, local_rank, clock_p
 
 def main():
     args = parse_args()
+    # ONE JSON line on stdout: libraries that write to file descriptor 1 (RCCL
+    # prints a version banner there) are sent to stderr; the line goes to the
+    # real stdout.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -480,7 +486,7 @@ def main():
             torch.cuda.empty_cache()
         if others:
             out["other_configs"] = others
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
         return
 
     # ------------------------------------------------------------------ N > 1
@@ -673,7 +679,7 @@ def main():
     dist.barrier()
     dist.destroy_process_group()
     if out is not None:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
 
 
 if __name__ == "__main__":
