@@ -116,6 +116,9 @@ def parse_args():
                          "read the input themselves (resident, default); or rank 0 owns it "
                          "and every step distributes it first: chunked broadcast overlapped "
                          "with compute (staged) / broadcast then compute (simple)")
+    ap.add_argument("--no-balance", action="store_true",
+                    help="N>1: keep equal tile ranges (default: after the warm-up passes the "
+                         "ranges are re-cut in proportion to each rank's measured kernel speed)")
     ap.add_argument("--no-broadcast-pass", action="store_true",
                     help="N>1: skip the extra broadcast-inclusive passes after the timed region")
     ap.add_argument("--chunks", type=int, default=8, help="broadcast chunks (staged)")
@@ -364,8 +367,9 @@ def main():
     import torch.distributed as dist
     import cuking_amd
     from cuking_amd.dist import (GpuStagedOps, PipelinedGather, all_pairs_king,
-                                 all_pairs_king_staged, gather_results_device,
-                                 rank_tile_share, tile_partition)
+                                 all_pairs_king_staged, gather_results,
+                                 gather_results_device,
+                                 rank_tile_share, tile_partition, weighted_tile_partition)
     from cuking_amd.synth import cohort_to_device, plan_cohort
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -532,6 +536,8 @@ def main():
     pending = [None]
     parity = [0]
 
+    my_tiles = list(my_tiles)
+
     def pipelined_step():
         # pass k: kernel into buffer k % 2, its gather starts behind it; then the
         # gather of pass k - 1 is collected while this pass's kernel runs
@@ -561,6 +567,11 @@ def main():
         if mode == "staged" and staged_ops is not None:
             gathered[0], _ = all_pairs_king_staged(staged_ops, n, tile, bits,
                                                    num_chunks=args.chunks)
+        elif mode == "resident" and args.kernel == "tiled":
+            # this rank's (possibly re-balanced) range, then the gather
+            out_ = compute_tiles(bits, *my_tiles)
+            gathered[0] = (gather_results_device(*out_) if device_gather
+                           else gather_results(*out_))
         else:
             gathered[0], _ = all_pairs_king(compute_tiles, num_tiles, bits,
                                             broadcast=mode != "resident")
@@ -569,11 +580,31 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    host_or_dev = "cpu" if rehearsal else dev
+    balance = {"applied": False}
+    for w in range(args.warmup):
+        if w == args.warmup - 1:
+            ctx.timing_reset()          # the last warm-up pass doubles as calibration
         step()
     if pipelined:
         drain()
     barrier()
+    if (args.warmup >= 1 and args.dist_mode == "resident" and args.kernel == "tiled"
+            and not args.no_balance):
+        # The GPUs of a node sustain different clocks under this load (several
+        # percent); with equal ranges the slowest sets the pace.  Re-cut the tile
+        # ranges in proportion to what each rank just measured for itself.
+        cal = ctx.timing_collect()
+        rate = torch.tensor([(my_tiles[1] - my_tiles[0]) / max(cal.king_ms, 1e-6)],
+                            dtype=torch.float64, device=host_or_dev)
+        rates = [torch.zeros_like(rate) for _ in range(world)]
+        dist.all_gather(rates, rate)
+        rates = [float(r) for r in rates]
+        balance.update(rank_tiles_per_ms=rates, spread=max(rates) / min(rates) - 1.0)
+        if min(rates) > 0 and balance["spread"] > 0.015:
+            my_tiles = weighted_tile_partition(num_tiles, rates)[rank]
+            balance["applied"] = True
+        barrier()
     ctx.timing_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -582,7 +613,6 @@ def main():
         drain()          # the last pass's records are on rank 0 before the clock stops
     barrier()
     elapsed = time.perf_counter() - t0
-    host_or_dev = "cpu" if rehearsal else dev
     t = torch.tensor([elapsed], dtype=torch.float64, device=host_or_dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t)
@@ -607,7 +637,6 @@ def main():
     if device_gather:
         gather_results_device(out_tiles[0], out_tiles[1])
     else:
-        from cuking_amd.dist import gather_results
         gather_results(*out_tiles)
     gather_ms = (time.perf_counter() - g0) * 1e3
 
@@ -671,6 +700,7 @@ def main():
                        "rank_kernel_ms_per_step": rank_kernel_ms,
                        "rank_prepare_ms_per_step": rank_prepare_ms,
                        "gather_ms_unpipelined": gather_ms,
+                       "tile_range_balance": balance,
                        "bitset_bytes_per_rank": int(bits.numel() * 8)},
             "with_broadcast": with_broadcast,
             "roofline": roofline,

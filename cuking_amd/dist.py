@@ -89,6 +89,24 @@ def tile_partition(num_tiles: int, world_size: int) -> List[Tuple[int, int]]:
     return out
 
 
+def weighted_tile_partition(num_tiles: int, weights) -> List[Tuple[int, int]]:
+    """Contiguous ranges proportional to ``weights`` (a rank's measured speed in
+    tiles per millisecond): the GPUs of one node differ by several percent in the
+    clock they sustain under this load, and with equal ranges the slowest one
+    sets the pace.  Exact cover of [0, num_tiles), monotone, every weight > 0."""
+    w = [float(x) for x in weights]
+    if not w or min(w) <= 0.0:
+        raise ValueError("weights must be positive")
+    total = sum(w)
+    out, begin, acc = [], 0, 0.0
+    for r, x in enumerate(w):
+        acc += x
+        end = num_tiles if r == len(w) - 1 else min(num_tiles, max(begin, round(num_tiles * acc / total)))
+        out.append((begin, end))
+        begin = end
+    return out
+
+
 def broadcast_bitset(bit_sets, src: int = 0, group=None) -> None:
     """Exchange step 1 (in place)."""
     import torch.distributed as dist

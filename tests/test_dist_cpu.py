@@ -326,3 +326,19 @@ def test_pipelined_gather_on_host_tensors(tmp_path):
     out = tmp_path / "res"
     mp.spawn(_status_ok_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
     assert all(Path(f"{out}.{r}").read_text() == "ok" for r in range(2))
+
+
+def test_weighted_tile_partition():
+    from cuking_amd.dist import tile_partition, weighted_tile_partition
+    for tiles in (0, 1, 7, 1000, 2_747_896):
+        for w in ([1.0], [1, 1, 1], [1.0, 0.9, 1.1, 1.0], [5, 1], [1.0] * 8,
+                  [0.97, 1.0, 1.02, 0.95, 1.0, 1.01, 0.99, 1.03]):
+            parts = weighted_tile_partition(tiles, w)
+            assert len(parts) == len(w) and parts[0][0] == 0 and parts[-1][1] == tiles
+            assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            assert all(b <= e for b, e in parts)
+            for (b, e), x in zip(parts, w):      # proportional to within a tile
+                assert abs((e - b) - tiles * x / sum(w)) <= 1.0 + 1e-9
+    assert weighted_tile_partition(1000, [1.0] * 8) == tile_partition(1000, 8)
+    with pytest.raises(ValueError):
+        weighted_tile_partition(10, [1.0, 0.0])

@@ -13,7 +13,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 LEAN="--cpu-seconds 0 --extra-configs none --no-clock-pass"
 python3 $REPO/bench.py "$@" > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --steps 5 --warmup 1 $LEAN "$@" > $OUT/trace_bench.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --steps 20 --warmup 3 $LEAN "$@" > $OUT/trace_bench.json 2> $OUT/trace.err
 pmc() {  # pmc <dir> <counters...>
   local d=$1; shift
   rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$d -- python3 $REPO/bench.py --steps 2 --warmup 1 $LEAN "${BENCH_ARGS[@]}" > /dev/null 2> $OUT/$d.err
