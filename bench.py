@@ -233,7 +233,8 @@ def roofline_block(args, ctx, *, launch_pairs, sites, wps, thr, king_ms, prepare
                 "SURVEY.md 8d) / measured kernel time; operands are re-used from LDS and "
                 "registers, so this exceeds 1.0 of HBM peak by design",
     }
-    prof = committed_profile(workload_key, kernel_name) if use_profile else {}
+    prof = (committed_profile(workload_key + (":full" if form == "full" else ""), kernel_name)
+            if use_profile else {})
     common = {
         "traffic": prof.get("traffic_bytes_per_launch"),
         "traffic_source": (f"committed rocprofv3 --pmc passes of this command "
