@@ -119,6 +119,9 @@ def parse_args():
     ap.add_argument("--no-balance", action="store_true",
                     help="N>1: keep equal tile ranges (default: after the warm-up passes the "
                          "ranges are re-cut in proportion to each rank's measured kernel speed)")
+    ap.add_argument("--no-single-gpu-pass", action="store_true",
+                    help="N>1: skip the one pass of the WHOLE workload on rank 0 alone that "
+                         "gives the single-GPU figure of the same run")
     ap.add_argument("--no-broadcast-pass", action="store_true",
                     help="N>1: skip the extra broadcast-inclusive passes after the timed region")
     ap.add_argument("--chunks", type=int, default=8, help="broadcast chunks (staged)")
@@ -668,6 +671,29 @@ def main():
                          "(all_pairs_king)") + "; one pass, records identical to the "
                                                "resident pass"}
 
+    # The single-GPU figure of the SAME run: rank 0 alone evaluates every pair
+    # once (the others wait), so that the strong-scaling ratio can be read off one
+    # JSON line instead of two runs on possibly different boxes.
+    single = None
+    if not args.no_single_gpu_pass and world > 1 and args.kernel == "tiled":
+        barrier()
+        if rank == 0:
+            index_flag.zero_()
+            torch.cuda.synchronize()
+            s0 = time.perf_counter()
+            ctx.compute_king(sm, wps, bits, thr, args.max_results, results,
+                             index_flag[0:1], index_flag[1:2])
+            torch.cuda.synchronize()
+            s1 = time.perf_counter() - s0
+            cnt1, ovf1 = index_flag.tolist()
+            same = (not ovf1) and records_of(results, cnt1).tobytes() == recs.tobytes()
+            if not same and not args.no_check:
+                raise SystemExit("single-GPU pass: records differ from the sharded pass")
+            single = {"seconds": s1, "value": pairs / s1, "unit": "sample-pairs/s",
+                      "what": "rank 0 alone, the whole workload, one pass after the timed "
+                              "region; records identical to the sharded pass"}
+        barrier()
+
     out = None
     if rank == 0:
         check_planted(recs, cohort, thr, args.no_check)
@@ -704,6 +730,7 @@ def main():
                        "tile_range_balance": balance,
                        "bitset_bytes_per_rank": int(bits.numel() * 8)},
             "with_broadcast": with_broadcast,
+            "single_gpu_same_run": single,
             "roofline": roofline,
             "cpu_baseline": None,
         }

@@ -20,6 +20,8 @@ ctx = cuking_amd.KingContext(0)
 t0 = time.time()
 for case in range(cases):
     n = int(rng.integers(2, 700)); m = int(rng.integers(1, 2500))
+    if rng.random() < 0.15:   # enough tiles for the XCD-aware order (launches of >= 64 tiles)
+        n = int(rng.integers(1400, 2300))
     k = int(rng.integers(1, 4)); shard = int(rng.integers(0, k * (k + 1) // 2))
     thr = float(rng.choice([-1e30, -0.2, 0.0, 0.03, 0.0884, 0.3]))
     variant = int(rng.integers(0, 6)); mode = int(rng.integers(-1, 2))
@@ -30,9 +32,12 @@ for case in range(cases):
         if rng.random() < 0.3: geno[1] = -1
     osm = pyoracle.submatrix(n, k, shard)
     bits = pyoracle.bitset_from_genotypes(geno, osm)
-    exp, _, _ = pyoracle.compute(osm, bits, thr)
+    exp, _, _ = pyoracle.compute(osm, bits, thr, threads=8)
     sm = cuking_amd.Submatrix(n, k, shard)
     ctx.set_kernel(kernel); ctx.set_option("variant", variant); ctx.set_option("counts_mode", mode)
+    ctx.set_option("xcd_swizzle", int(rng.integers(0, 2)))
+    ctx.set_option("band_rows", int(rng.choice([0, 0, 1, 3, 5, 17])))
+    ctx.set_option("split_wgs", int(rng.choice([0, 256, 256])))
     d_bits = (ctx.upload_bitset(bits) if bits.shape[0] else
               torch.zeros(2, dtype=torch.int64, device="cuda:0"))
     wps = cuking_amd.words_per_sample(m)

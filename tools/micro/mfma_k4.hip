@@ -90,6 +90,22 @@ __device__ __forceinline__ void row_pre(RowPre &p, uint32_t ones) {
   p.rwL = shl1(rw); p.rwR = shr1(rw);
   p.hetB = shr2(p.het); p.homB = shr2(p.hom);
 }
+// The same in the two halves the balanced pipeline (MODE 2) spreads over phases:
+// A = what site sets 0, 1 need, B = what sets 2, 3 need.
+__device__ __forceinline__ void row_pre_a(RowPre &p, uint32_t ones) {
+  const uint4 aw = ind<kA>(p.het, p.hom, ones), rw = ind<kR>(p.het, p.hom, ones);
+  p.awL = shl1(aw);
+  p.rwL = shl1(rw);
+}
+__device__ __forceinline__ void row_pre_b(RowPre &p, uint32_t ones) {
+  // (recomputes the indicator words: 8 more v_bitop3 per block and k-step than
+  //  row_pre, in exchange for not keeping them alive across two phases)
+  const uint4 aw = ind<kA>(p.het, p.hom, ones), rw = ind<kR>(p.het, p.hom, ones);
+  p.awR = shr1(aw);
+  p.rwR = shr1(rw);
+  p.hetB = shr2(p.het);
+  p.homB = shr2(p.hom);
+}
 // Column side: stored with nibble bits 0<->1, 2<->3 exchanged.
 struct ColPre {
   uint4 het, hom;
@@ -100,6 +116,8 @@ __device__ __forceinline__ void col_pre(ColPre &p) {
   p.hetA = shl1(p.het); p.homA = shl1(p.hom);
   p.hetB = shr1(p.het); p.homB = shr1(p.hom);
 }
+__device__ __forceinline__ void col_pre_a(ColPre &p) { p.hetA = shl1(p.het); p.homA = shl1(p.hom); }
+__device__ __forceinline__ void col_pre_b(ColPre &p) { p.hetB = shr1(p.het); p.homB = shr1(p.hom); }
 // Fragment sets of site p (0..3) of every nibble.  Row: [0] H (= t), [1] D,
 // [2] U = H + 2A, [3] V = 2R + H.  Column: [0] R, [1] A, [2] D, [3] H.
 template <int P>
@@ -202,6 +220,52 @@ __global__ __launch_bounds__(256) void rate_kernel(const uint4 *src, float *out,
       FRAGS(1, Y) MMA16(Y)
       FRAGS(2, X) MMA16(X)
       FRAGS(3, Y) MMA16(Y)
+    }
+  } else if (MODE == 2 || MODE == 3) {
+    // Balanced pipeline: every phase carries 16 MFMAs and ~88-96 VALU.  The words
+    // sets 2, 3 need are derived while set 0 multiplies; the raw words are dead
+    // after that, so the next k-step's LDS reads go out while set 2 multiplies
+    // and what its sets 0, 1 need is derived behind them.
+    RowPre Rn[2]; ColPre Cn[2];
+    {
+      const uint4 *t = lds + g * (2 * 256);
+      LOAD_RAW(t)
+      _Pragma("unroll") for (int b = 0; b < 2; ++b) { row_pre_a(R[b], ones); col_pre_a(C[b]); }
+      FRAGS(0, X)
+    }
+    for (int it = 0; it < iters; ++it) {
+      const uint4 *t = lds + ((it + 1) & 1) * (2 * 2 * 256) + g * (2 * 256);
+      // set 0 multiplies; B-side words, then set 1
+      _Pragma("unroll") for (int b = 0; b < 2; ++b) { row_pre_b(R[b], ones); col_pre_b(C[b]); }
+      FRAGS(1, Y)
+      MMA16(X)
+      PACE(8, 6) PACE(8, 7)
+      __builtin_amdgcn_sched_barrier(0);
+      // set 1 multiplies; set 2
+      FRAGS(2, X)
+      MMA16(Y)
+      PACE(16, 4)
+      __builtin_amdgcn_sched_barrier(0);
+      // set 2 multiplies; next k-step's raw words, set 3
+      if (MODE == 3) __syncthreads();
+      _Pragma("unroll") for (int b = 0; b < 2; ++b) {
+        Rn[b].het = t[0 * 256 + wr + b * 32 + lr]; Rn[b].hom = t[1 * 256 + wr + b * 32 + lr];
+        Cn[b].het = t[0 * 256 + wc + b * 32 + lr]; Cn[b].hom = t[1 * 256 + wc + b * 32 + lr];
+      }
+      FRAGS(3, Y)
+      MMA16(X)
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      PACE(16, 4)
+      __builtin_amdgcn_sched_barrier(0);
+      // set 3 multiplies; A-side words of the next k-step, its set 0
+      _Pragma("unroll") for (int b = 0; b < 2; ++b) {
+        R[b].het = Rn[b].het; R[b].hom = Rn[b].hom; C[b].het = Cn[b].het; C[b].hom = Cn[b].hom;
+        row_pre_a(R[b], ones); col_pre_a(C[b]);
+      }
+      FRAGS(0, X)
+      MMA16(Y)
+      PACE(8, 6) PACE(8, 7)
+      __builtin_amdgcn_sched_barrier(0);
     }
   } else {
     {
@@ -351,7 +415,11 @@ int main() {
   const size_t lds_bytes = 2 * 2 * 2 * 256 * sizeof(uint4);
   CHECK(hipFuncSetAttribute((const void *)rate_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   CHECK(hipFuncSetAttribute((const void *)rate_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  CHECK(hipFuncSetAttribute((const void *)rate_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  CHECK(hipFuncSetAttribute((const void *)rate_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   if (rate_of(rate_kernel<0>, 0, d_src, d_out)) return 1;
   if (rate_of(rate_kernel<1>, 1, d_src, d_out)) return 1;
+  if (rate_of(rate_kernel<2>, 2, d_src, d_out)) return 1;
+  if (rate_of(rate_kernel<3>, 3, d_src, d_out)) return 1;
   return bad != 0;
 }
