@@ -113,6 +113,21 @@ __device__ __attribute__((noinline)) void lean_epilogue_call(
   lean_epilogue_pair(c, valid, li, lj, het_i, het_j, both_het, opp, lane);
 }
 
+// The record append of the full form, out of line as well -- here for
+// correctness: inlined 64 times, the wave-level aggregation the compiler builds
+// around the atomic counter (whole-wave-mode temporaries) sat in the middle of
+// ~500 live registers, and the remainder-split instantiation then returned
+// wrong sums for whole tiles whenever only a few lanes emitted (staged
+// rectangles, threshold 0.0884: tools/fuzz_split.py seed 1 case 3; with every
+// lane emitting, or out of line, the same sums are right).  The decision whether
+// to call is wave-uniform.
+__device__ __attribute__((noinline)) void full_emit_call(
+    const EmitCtx c, uint32_t li, uint32_t lj, float kin, uint32_t ibs0, uint32_t ibs1,
+    uint32_t ibs2) {
+  emit_result(c.i_begin + li, c.j_begin + lj, kin, ibs0, ibs1, ibs2, c.max_results, c.results,
+              c.result_index, c.result_overflow);
+}
+
 // `n` MFMAs, each followed by `v` VALU instructions (scheduling request).
 #define CUKING_PACE(n, v)                                                      \
   _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {                         \
@@ -151,7 +166,7 @@ template <bool FULL, bool SPLIT, int ABLATE = 0>
 __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   constexpr int NSTAGE = kStages;
   constexpr int NQ = 4;              // sums of the main loop: opp, bh, hi, hj
-  constexpr int NSUM = FULL ? 5 : 4; // + hom_hom from the full form's second pass
+  constexpr int NSUM = FULL ? 5 : 4; // + hom_hom from the full form's extra pass
   constexpr int BI = 2;              // 32-row blocks of the wavefront
   extern __shared__ uint4 lds[];  // [NSTAGE][side][k-group][plane][128]
 
@@ -682,9 +697,22 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
         const bool valid = li < a.geo.num_rows && lj < a.geo.num_cols &&
                            a.i_begin + li < a.j_begin + lj;
         if (FULL) {
-          full_epilogue_pair(a, valid, li, lj, (uint32_t)acc[bi][bj][2][r],
-                             (uint32_t)acc[bi][bj][3][r], (uint32_t)acc[bi][bj][1][r],
-                             (uint32_t)acc[bi][bj][0][r], (uint32_t)hh[r]);
+          // cuking.cu:284-313 with all five sums at hand
+          const uint32_t het_i = (uint32_t)acc[bi][bj][2][r], het_j = (uint32_t)acc[bi][bj][3][r];
+          const uint32_t both_het = (uint32_t)acc[bi][bj][1][r], opp = (uint32_t)acc[bi][bj][0][r];
+          const uint32_t hom_hom = (uint32_t)hh[r];
+          if (a.dense_counts != nullptr) {
+            full_epilogue_pair(a, valid, li, lj, het_i, het_j, both_het, opp, hom_hom);
+          } else {
+            const float kin = king_kinship(het_i, het_j, both_het, opp);
+            const bool emit = valid && kin > a.kin_threshold;
+            if (__ballot(emit) != 0) {      // wave-uniform
+              const uint32_t conc = hom_hom - opp;
+              const uint32_t shared = het_i + het_j - both_het + hom_hom;
+              const uint32_t ibs2 = conc + both_het;
+              if (emit) full_emit_call(emit_ctx, li, lj, kin, opp, shared - opp - ibs2, ibs2);
+            }
+          }
         } else {
           // Nearly every pair fails the threshold: decide that on the float
           // sums without the IEEE divide, and only when some lane of the

@@ -840,3 +840,45 @@ def test_tile_order_options_do_not_change_results(ctx, oracle, split_wgs):
         ctx.set_option("xcd_swizzle", 1)
         ctx.set_option("band_rows", 0)
         ctx.set_option("split_wgs", 256)
+
+
+@pytest.mark.parametrize("counts_mode", [0, 1])
+def test_staged_rectangles_with_few_emitting_lanes(ctx, counts_mode):
+    """Staged rectangles (invalid tile slots below the diagonal) x remainder split
+    with pieces longer than a tile x a threshold only a handful of pairs pass:
+    the combination in which an inlined record append once corrupted the sums of
+    whole tiles in the full form (tools/fuzz_split.py seed 1, case 3)."""
+    import torch
+    from cuking_amd.dist import GpuStagedOps, staged_schedule
+    from oracle import pyoracle
+    select(ctx, "tiled", 5, counts_mode)
+    n, m, thr, seed = 514, 17182, 0.0884, 1003
+    cohort = plan_cohort(n, seed)
+    kind, pa, pb = cohort_to_device(cohort, 0)
+    wps = cuking_amd.words_per_sample(m)
+    d_bits = ctx.synth_bitset(seed, kind, pa, pb, 0, n, m)
+    torch.cuda.synchronize()
+    bits = np.ascontiguousarray(d_bits.cpu().numpy().view(np.uint64))
+    exp, _, _ = pyoracle.compute(pyoracle.submatrix(n), bits, thr, threads=16)
+    assert 20 < len(exp) < 100
+    sm = cuking_amd.Submatrix(n)
+    try:
+        for wgs, world in ((16, 1), (16, 2), (3, 3), (64, 1), (256, 2), (1, 1)):
+            ctx.set_option("split_wgs", wgs)
+            parts = []
+            for rank in range(world):
+                ops = GpuStagedOps(ctx, sm, wps, d_bits, thr, len(exp) + 8, num_streams=1)
+                ops.begin()
+                for (c0, c1), rect in staged_schedule(n, ctx.tile_samples(), world, rank, 1):
+                    if rect is not None:
+                        ops.prepare(c0, c1)
+                        ops.compute_rect(*rect)
+                res, cnt, ovf = ops.finish()
+                assert ovf == 0
+                parts.append(res[:cnt].cpu().numpy().view(np.uint32).reshape(-1).view(
+                    cuking_amd.KING_RESULT_DTYPE).copy())
+            merged = cuking_amd.sort_results(np.ascontiguousarray(np.concatenate(parts)))
+            assert merged.tobytes() == exp.tobytes(), (wgs, world)
+    finally:
+        ctx.set_option("split_wgs", 256)
+        ctx.set_option("counts_mode", -1)
