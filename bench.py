@@ -100,6 +100,9 @@ def parse_args():
     ap.add_argument("--kernel", default="tiled", choices=["tiled", "stream"])
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--band-rows", type=int, default=-1)
+    ap.add_argument("--split-wgs", type=int, default=-1,
+                    help="matrix-core kernel: pieces the remainder of a short launch is cut "
+                         "into (-1 = library default, one per CU; 0 = never split)")
     ap.add_argument("--xcd-swizzle", type=int, default=-1, choices=[-1, 0, 1],
                     help="matrix-core kernel: consecutive tiles per XCD (-1 = library default)")
     ap.add_argument("--counts-mode", type=int, default=-1, choices=[-1, 0, 1],
@@ -427,6 +430,8 @@ def main():
         ctx.set_option("counts_mode", args.counts_mode)
     if args.xcd_swizzle >= 0:
         ctx.set_option("xcd_swizzle", args.xcd_swizzle)
+    if args.split_wgs >= 0:
+        ctx.set_option("split_wgs", args.split_wgs)
     ctx.timing_enable(True)
     dtype_of = lambda roof: ("fp4 products, f32 accumulate (exact integers)"
                              if roof["bound"] == "mfma" else "u32")

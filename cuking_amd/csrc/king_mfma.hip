@@ -63,8 +63,15 @@ constexpr int kPiecesPerWave = 4;            // 16 x 1 KiB per stage, 4 wavefron
 // is multiplied, i.e. kStages - 2 k-steps (~1.4 us each) of HBM latency are
 // covered.
 constexpr int kStages = CUKING_MFMA_STAGES;
+// Lean form (no LDS needed for a parked sum): two more stages, which is what it
+// takes to hand stages over with one barrier per TWO k-steps.
+#ifndef CUKING_MFMA_PAIRED
+#define CUKING_MFMA_PAIRED 1
+#endif
+constexpr bool kPairedSync = CUKING_MFMA_PAIRED != 0 && kStages == 6;
+constexpr int kStagesPaired = 8;
 // s_waitcnt vmcnt(N) immediate, N = DMAs of the kStages - 2 younger stages.
-constexpr int kYoungerDmas = (kStages - 2) * kPiecesPerWave;
+constexpr int kYoungerDmas = 4 * kPiecesPerWave;  // both hand-over schemes, see the kernel
 static_assert(kYoungerDmas < 64, "vmcnt is a 6-bit counter");
 constexpr int kWaitStage = 0x0F70 | (kYoungerDmas & 15) | ((kYoungerDmas >> 4) << 14);
 
@@ -164,7 +171,11 @@ __device__ __forceinline__ uint32_t split_owner(uint64_t u, uint64_t units,
 // 3 = epilogue reduced to one store per lane (prices the kinship/threshold pass).
 template <bool FULL, bool SPLIT, int ABLATE = 0>
 __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
-  constexpr int NSTAGE = kStages;
+  // Lean form: 8 LDS stages and ONE stage barrier per two k-steps (below); the
+  // full form parks its fifth sum in the LDS behind the stages and keeps 6
+  // stages with a barrier per k-step.
+  constexpr bool PAIRED = !FULL && kPairedSync;
+  constexpr int NSTAGE = PAIRED ? kStagesPaired : kStages;
   constexpr int NQ = 4;              // sums of the main loop: opp, bh, hi, hj
   constexpr int NSUM = FULL ? 5 : 4; // + hom_hom from the full form's extra pass
   constexpr int BI = 2;              // 32-row blocks of the wavefront
@@ -453,8 +464,23 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   CUKING_MMA1(F, X, 2, 3, 2) CUKING_MMA1(F, X, 3, 2, 3)
 #define CUKING_MMA4(F, X) CUKING_MMA1(F, X, 1, 0, 0)
 
+  // Stage hand-over.  Unpaired (full form): stage s + NSTAGE - 1 is requested
+  // while stage s is multiplied, into the buffer stage s - 1 left, and every
+  // k-step ends with the counted wait + barrier.  Paired (lean form, 8 stages):
+  // the barrier comes only at the end of ODD k-steps and then covers the next
+  // TWO stages.  A request may only overwrite a buffer whose last readers are
+  // separated from it by a barrier; the reads of stage k happen at the end of
+  // k-step k - 1, so with barriers B(j) at the end of odd j an even k-step i
+  // may request stage i + 7 (buffer of stage i - 1, read at the end of i - 2,
+  // B(i - 1) in between) and an odd k-step i stage i + 5 (buffer of stage
+  // i - 3, read at the end of i - 4, B(i - 2) in between).  Request order is
+  // then 0..5, 7, 6, 9, 8, ...: when B(s) (s odd) waits for all but the 16
+  // youngest requests of the wavefront, those are stages s+4, s+3, s+6, s+5,
+  // i.e. stages s+1 and s+2 -- read at the end of k-steps s and s+1 -- have
+  // landed: the same vmcnt(16) as the unpaired form.
+  constexpr int kPrologueStages = PAIRED ? NSTAGE - 2 : NSTAGE - 1;
 #pragma unroll
-  for (int st = 0; st < NSTAGE - 1; ++st) issue_stage(st, st);
+  for (int st = 0; st < kPrologueStages; ++st) issue_stage(st, st);
   stage_sync();
 
   {
@@ -475,50 +501,64 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     // reload whose first use is inside the loop would put the compiler's
     // s_waitcnt vmcnt(0) there, draining the DMA pipeline in every iteration.
     asm volatile("" : "+v"(row_off), "+v"(col_off), "+v"(lane16));
-    for (uint32_t step = 0; step + 1 < num_steps; ++step) {
-      const uint32_t nbuf = buf == NSTAGE - 1 ? 0 : buf + 1;
-      const uint32_t fbuf = buf == 0 ? NSTAGE - 1 : buf - 1;  // free since the last barrier
-      // f = 0 multiplies, f = 1 is built
-      CUKING_EXPAND(Y, A, B, m2)
-      CUKING_MMA16(0, X)
-      CUKING_PACE(16, 4)
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        issue_piece(step + NSTAGE - 1, fbuf, r);
-        acc[r >> 1][r & 1][0] = mma<0>(Xa[r >> 1][1], Xb[r & 1][0], acc[r >> 1][r & 1][0]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // f = 1 multiplies (unscaled), f = 2 and the shifted words are built
-      CUKING_EXPAND(X, A, B, m4)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          As[b][p] = shr3(A[b][p]);
-          Bs[b][p] = shr3(B[b][p]);
-        }
-      CUKING_MMA16(1, Y)
-      CUKING_MMA4(1, Y)
-      CUKING_PACE(20, 5)
-      __builtin_amdgcn_sched_barrier(0);
-      // f = 2 multiplies, f = 3 is built from the shifted words
-      CUKING_EXPAND(Y, As, Bs, m1)
-      CUKING_MMA16(2, X)
-      CUKING_MMA4(2, X)
-      CUKING_PACE(16, 4) CUKING_PACE(4, 0)
-      __builtin_amdgcn_sched_barrier(0);
-      // f = 3 multiplies; next k-step: hand-over, LDS reads, f = 0
-      stage_sync();
-      CUKING_LOAD_RAW(nbuf)
-      CUKING_EXPAND(X, A, B, m1)
-      CUKING_MMA16(3, Y)
-      CUKING_MMA4(3, Y)
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-      CUKING_PACE(4, 0) CUKING_PACE(16, 4)
-      __builtin_amdgcn_sched_barrier(0);
-      buf = nbuf;
+    // One k-step: requests stage STEP + AHEAD into the buffer BACK behind the
+    // current one; SYNC = hand stages over (wait + barrier) before the next
+    // k-step's LDS reads.
+#define CUKING_KSTEP(STEP, SYNC, AHEAD, BACK)                                  \
+    {                                                                          \
+      const uint32_t nbuf = buf == NSTAGE - 1 ? 0 : buf + 1;                   \
+      const uint32_t dbuf = buf >= (BACK) ? buf - (BACK) : buf + NSTAGE - (BACK); \
+      /* f = 0 multiplies, f = 1 is built */                                   \
+      CUKING_EXPAND(Y, A, B, m2)                                               \
+      CUKING_MMA16(0, X)                                                       \
+      CUKING_PACE(16, 4)                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                       \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) {                          \
+        issue_piece((STEP) + (AHEAD), dbuf, r);                                \
+        acc[r >> 1][r & 1][0] =                                                \
+            mma<0>(Xa[r >> 1][1], Xb[r & 1][0], acc[r >> 1][r & 1][0]);        \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+      }                                                                        \
+      /* f = 1 multiplies (unscaled), f = 2 and the shifted words are built */ \
+      CUKING_EXPAND(X, A, B, m4)                                               \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b)                            \
+      _Pragma("unroll") for (int p = 0; p < 2; ++p) {                          \
+        As[b][p] = shr3(A[b][p]);                                              \
+        Bs[b][p] = shr3(B[b][p]);                                              \
+      }                                                                        \
+      CUKING_MMA16(1, Y)                                                       \
+      CUKING_MMA4(1, Y)                                                        \
+      CUKING_PACE(20, 5)                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                       \
+      /* f = 2 multiplies, f = 3 is built from the shifted words */            \
+      CUKING_EXPAND(Y, As, Bs, m1)                                             \
+      CUKING_MMA16(2, X)                                                       \
+      CUKING_MMA4(2, X)                                                        \
+      CUKING_PACE(16, 4) CUKING_PACE(4, 0)                                     \
+      __builtin_amdgcn_sched_barrier(0);                                       \
+      /* f = 3 multiplies; next k-step: hand-over, LDS reads, f = 0 */         \
+      if (SYNC) stage_sync();                                                  \
+      CUKING_LOAD_RAW(nbuf)                                                    \
+      CUKING_EXPAND(X, A, B, m1)                                               \
+      CUKING_MMA16(3, Y)                                                       \
+      CUKING_MMA4(3, Y)                                                        \
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                       \
+      CUKING_PACE(4, 0) CUKING_PACE(16, 4)                                     \
+      __builtin_amdgcn_sched_barrier(0);                                       \
+      buf = nbuf;                                                              \
     }
+    if constexpr (PAIRED) {
+      uint32_t step = 0;
+      for (; step + 2 < num_steps; step += 2) {
+        CUKING_KSTEP(step, false, NSTAGE - 1, 1)
+        CUKING_KSTEP(step + 1, true, NSTAGE - 3, 3)
+      }
+      if (step + 1 < num_steps) CUKING_KSTEP(step, false, NSTAGE - 1, 1)
+    } else {
+      for (uint32_t step = 0; step + 1 < num_steps; ++step)
+        CUKING_KSTEP(step, true, NSTAGE - 1, 1)
+    }
+#undef CUKING_KSTEP
     // last k-step: nothing left to fetch
     CUKING_EXPAND(Y, A, B, m2)
     CUKING_MMA16(0, X)
@@ -738,7 +778,9 @@ template <bool FULL, bool SPLIT, int ABLATE = 0>
 hipError_t launch_shape(const TiledArgs &args, uint64_t num_blocks,
                         uint32_t lds_bytes, hipStream_t stream) {
   auto kernel = king_mfma_kernel<FULL, SPLIT, ABLATE>;
+  // (the caller's figure is the 6-stage one of the variant table)
   if (FULL) lds_bytes += kMfmaParkBytes;  // the parked fifth sum, behind the stages
+  else if (kPairedSync) lds_bytes = kStagesPaired * kStageU4 * sizeof(uint4);
   static DeviceOnce attr_set;  // per device, see king_device.h
   if (!attr_set.done()) {
     hipError_t e = hipFuncSetAttribute(
