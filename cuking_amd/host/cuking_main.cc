@@ -32,6 +32,7 @@
 #include "multi_gpu.h"
 #include "parquet_io.h"
 #include "schedule.h"
+#include "synth_plan.h"
 #include "thread_pool.h"
 
 namespace {
@@ -304,14 +305,23 @@ Status Run(const Flags &flags) {
     const std::string err = cuking_host::ValidateFlags(flags);
     if (!err.empty()) return InvalidArgument(err);
   }
+  const bool synthetic = !flags.synthetic.empty();
   std::string input_dir, output_dir;
-  RETURN_IF_ERROR(ResolveUri(flags.input_uri, &input_dir));
+  if (!synthetic) RETURN_IF_ERROR(ResolveUri(flags.input_uri, &input_dir));
   RETURN_IF_ERROR(ResolveUri(flags.output_uri, &output_dir));
 
   StopWatch sw;
   std::cout << "Reading metadata..." << std::flush;
   cuking_host::Metadata metadata;
-  {
+  if (synthetic) {
+    metadata.num_sites = flags.synth_sites;
+    metadata.samples.reserve(flags.synth_samples);
+    char name[16];
+    for (uint32_t k = 0; k < flags.synth_samples; ++k) {
+      snprintf(name, sizeof(name), "S%07u", k);
+      metadata.samples.emplace_back(name);
+    }
+  } else {
     const std::string err =
         cuking_host::ReadMetadataFile(input_dir + "/metadata.json", &metadata);
     if (!err.empty()) return FailedPrecondition(err);
@@ -336,7 +346,11 @@ Status Run(const Flags &flags) {
       (size_t)words_per_sample * cuking_submatrix_num_samples(&sm);
   const size_t bit_set_bytes = bit_set_words * sizeof(uint64_t);
   const bool dump_only = !flags.dump_bitset.empty();
-  const bool pack_on_device = flags.pack == "device" && !dump_only;
+  if (dump_only && synthetic)
+    return InvalidArgument("--dump_bitset needs input tables, not --synthetic");
+  // (a synthetic cohort is generated on the GPU: from here on it is a bitset
+  //  that already sits in device memory, like a device-packed one)
+  const bool pack_on_device = (flags.pack == "device" || synthetic) && !dump_only;
 
   DeviceBuffers buf;
   std::vector<uint64_t> dump_bits;  // --dump_bitset: plain host memory, no GPU
@@ -352,7 +366,9 @@ Status Run(const Flags &flags) {
     // (with --num_gpus and host pack every rank allocates its own copy later)
     if (!multi_gpu || pack_on_device)
       RETURN_IF_ERROR(FromAbi(cuking_device_alloc(buf.ctx, bit_set_bytes, &buf.d_bits)));
-    if (pack_on_device) {
+    if (synthetic) {
+      // every word is written by the generator
+    } else if (pack_on_device) {
       RETURN_IF_ERROR(FromAbi(
           cuking_memset_async(buf.ctx, buf.d_bits, 0xFF, bit_set_bytes, nullptr)));
     } else {
@@ -366,14 +382,44 @@ Status Run(const Flags &flags) {
       dump_only ? dump_bits.data() : static_cast<uint64_t *>(buf.host_bits);
   Done(&sw);
 
-  std::cout << "Listing input files..." << std::flush;
   std::vector<std::pair<std::string, size_t>> input_files;
-  RETURN_IF_ERROR(ListParquetFiles(input_dir, &input_files));
-  Done(&sw);
-  if (input_files.empty()) return FailedPrecondition("No input files found");  // :542-544
-  std::cout << "Found " << input_files.size() << " input files." << std::endl;
+  if (!synthetic) {
+    std::cout << "Listing input files..." << std::flush;
+    RETURN_IF_ERROR(ListParquetFiles(input_dir, &input_files));
+    Done(&sw);
+    if (input_files.empty()) return FailedPrecondition("No input files found");  // :542-544
+    std::cout << "Found " << input_files.size() << " input files." << std::endl;
+  }
+  const bool device_pack = pack_on_device && !synthetic;  // triples packed by the GPU
 
-  std::cout << "Processing Parquet tables..." << std::flush;
+  std::cout << (synthetic ? "Synthesising genotypes on the GPU..." : "Processing Parquet tables...")
+            << std::flush;
+  if (synthetic) {
+    // Founders + planted relatives (synth_plan.h), genotypes from the device
+    // generator, straight into the reference layout: rows of the shard first,
+    // then its columns (cuking.cu:171-175).
+    const cuking_host::CohortPlan plan =
+        cuking_host::PlanCohort(num_samples, flags.synth_seed);
+    void *d_plan = nullptr;
+    const size_t plan_bytes = (size_t)num_samples * sizeof(uint32_t);
+    RETURN_IF_ERROR(FromAbi(cuking_device_alloc(buf.ctx, 3 * plan_bytes, &d_plan)));
+    uint32_t *d_kind = static_cast<uint32_t *>(d_plan);
+    uint32_t *d_pa = d_kind + num_samples, *d_pb = d_pa + num_samples;
+    cuking_status st = cuking_copy_to_device(buf.ctx, d_kind, plan.kind.data(), plan_bytes, nullptr);
+    if (st == CUKING_OK) st = cuking_copy_to_device(buf.ctx, d_pa, plan.pa.data(), plan_bytes, nullptr);
+    if (st == CUKING_OK) st = cuking_copy_to_device(buf.ctx, d_pb, plan.pb.data(), plan_bytes, nullptr);
+    uint64_t *d_bits = static_cast<uint64_t *>(buf.d_bits);
+    if (st == CUKING_OK)
+      st = cuking_synth_bitset(buf.ctx, flags.synth_seed, d_kind, d_pa, d_pb, sm.i_begin, sm.i_end,
+                               metadata.num_sites, words_per_sample, d_bits, nullptr);
+    if (st == CUKING_OK && sm.i_begin != sm.j_begin)
+      st = cuking_synth_bitset(buf.ctx, flags.synth_seed, d_kind, d_pa, d_pb, sm.j_begin, sm.j_end,
+                               metadata.num_sites, words_per_sample,
+                               d_bits + (size_t)(sm.i_end - sm.i_begin) * words_per_sample, nullptr);
+    if (st == CUKING_OK) st = cuking_stream_synchronize(buf.ctx, nullptr);
+    cuking_device_free(buf.ctx, d_plan);
+    RETURN_IF_ERROR(FromAbi(st));
+  }
   std::atomic<size_t> num_processed(0), num_triples(0);
   std::atomic<uint64_t> decode_us(0), pack_us(0);  // summed over reader threads
   auto now_us = []() {
@@ -384,7 +430,7 @@ Status Run(const Flags &flags) {
   std::vector<std::unique_ptr<DevicePacker>> packers;
   uint32_t *d_pack_status = nullptr;
   std::atomic<size_t> next_packer(0);
-  if (pack_on_device) {
+  if (device_pack) {
     RETURN_IF_ERROR(FromAbi(cuking_device_alloc(buf.ctx, sizeof(uint32_t),
                                                 reinterpret_cast<void **>(&d_pack_status))));
     RETURN_IF_ERROR(FromAbi(
@@ -398,7 +444,7 @@ Status Run(const Flags &flags) {
   std::string setup_error;
   std::thread setup_thread;
   std::shared_future<void> setup_done;
-  if (pack_on_device) {
+  if (device_pack) {
     std::promise<void> promise;
     setup_done = promise.get_future().share();
     setup_thread = std::thread([&, promise = std::move(promise)]() mutable {
@@ -441,7 +487,7 @@ Status Run(const Flags &flags) {
         const size_t n = t.row_idx.size();
         const uint64_t t_decoded = now_us();
         decode_us += t_decoded - t_begin;
-        if (!pack_on_device) {
+        if (!device_pack) {
           if (cuking_pack_host(&sm, words_per_sample, host_bits, t.row_idx.data(),
                                t.col_idx.data(), t.n_alt_alleles.data(), n) != CUKING_OK)
             return std::string("FAILED_PRECONDITION\n") + cuking_last_error() + " in " +
@@ -479,7 +525,7 @@ Status Run(const Flags &flags) {
               << " triples) to " << flags.dump_bitset << std::endl;
     return Status::Ok();
   }
-  if (pack_on_device) {
+  if (device_pack) {
     for (auto &p : packers) {
       const std::string msg = p->Finish();
       if (!msg.empty()) return {"INTERNAL", msg};
@@ -494,7 +540,7 @@ Status Run(const Flags &flags) {
       return FailedPrecondition("Invalid value for n_alt_alleles encountered");
     if (pack_status & 2u)
       return InvalidArgument("row_idx outside the padded sites encountered");
-  } else if (!multi_gpu) {
+  } else if (!multi_gpu && !synthetic) {
     RETURN_IF_ERROR(FromAbi(cuking_copy_to_device(buf.ctx, buf.d_bits, buf.host_bits,
                                                   bit_set_bytes, nullptr)));
     RETURN_IF_ERROR(FromAbi(cuking_stream_synchronize(buf.ctx, nullptr)));
@@ -624,7 +670,8 @@ Status Run(const Flags &flags) {
             << packer_stats.wait_us.load() * 1e-6 << ", \"narrow\": "
             << packer_stats.narrow_us.load() * 1e-6 << ", \"enqueue\": "
             << packer_stats.enqueue_us.load() * 1e-6 << "}"
-            << ", \"pack\": \"" << flags.pack << "\", \"reader_threads\": "
+            << ", \"pack\": \"" << (synthetic ? "synthetic" : flags.pack)
+            << "\", \"reader_threads\": "
             << flags.num_reader_threads << ", \"read_pack_seconds\": " << read_pack_seconds
             << ", \"triples_per_second\": " << std::setprecision(1)
             << (read_pack_seconds > 0 ? num_triples.load() / read_pack_seconds : 0.0)

@@ -56,6 +56,8 @@ std::string Usage() {
          "  --multi_gpu_mode=auto|staged|simple  broadcast overlapped with compute "
          "(diagonal shards) or broadcast then tile ranges\n"
          "  --bcast_chunks=N       pieces the bitset broadcast is cut into (default 8)\n"
+         "  --synthetic=N,M[,SEED] instead of --input_uri: synthetic cohort of N samples x M "
+         "sites generated on the GPU (founders + planted relatives)\n"
          "  --print_schedule       diagnostic: print the multi-GPU schedule (JSON) and "
          "exit before any GPU work\n"
          "  --dump_bitset=FILE     diagnostic: write the packed bitset (raw "
@@ -142,6 +144,27 @@ std::string ParseFlags(int argc, char **argv, Flags *flags) {
       if (!need_value() || (value != "auto" && value != "staged" && value != "simple"))
         return "Illegal value '" + value + "' specified for flag 'multi_gpu_mode'";
       flags->multi_gpu_mode = value;
+    } else if (name == "synthetic") {
+      if (!need_value()) return "Missing value for --synthetic";
+      uint64_t parts[3] = {0, 0, flags->synth_seed};
+      size_t count = 0, pos = 0;
+      bool ok = true;
+      while (ok && pos <= value.size() && count < 3) {
+        const size_t comma = value.find(',', pos);
+        const std::string item =
+            value.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+        ok = ParseUnsigned(item, count < 2 ? 0xFFFFFFFFull : UINT64_MAX, &parts[count]);
+        ++count;
+        if (comma == std::string::npos) break;
+        pos = comma + 1;
+        if (count == 3) ok = false;  // a fourth item
+      }
+      if (!ok || count < 2 || parts[0] == 0 || parts[1] == 0)
+        return "Illegal value '" + value + "' specified for flag 'synthetic' (N,M[,seed])";
+      flags->synthetic = value;
+      flags->synth_samples = (uint32_t)parts[0];
+      flags->synth_sites = (uint32_t)parts[1];
+      flags->synth_seed = parts[2];
     } else if (name == "print_schedule") {
       if (has_value && value != "true" && value != "1")
         return "Illegal value '" + value + "' specified for flag 'print_schedule'";
@@ -158,7 +181,8 @@ std::string ParseFlags(int argc, char **argv, Flags *flags) {
 }
 
 std::string ValidateFlags(const Flags &f) {
-  if (f.input_uri.empty()) return "No input URI specified";          // :438-440
+  if (f.input_uri.empty() && f.synthetic.empty())
+    return "No input URI specified";                                 // :438-440
   if (f.output_uri.empty()) return "No output URI specified";        // :444-446
   if (f.num_reader_threads == 0) return "Invalid number of reader threads";  // :450-452
   if (f.split_factor == 0) return "Invalid split factor";            // :455-457

@@ -33,6 +33,11 @@ struct Flags {
   uint32_t num_gpus = 0;
   std::string multi_gpu_mode = "auto";  // auto | staged | simple
   uint32_t bcast_chunks = 8;
+  // "N,M[,seed]": no input tables; the cohort of synth_plan.h is generated on
+  // the GPU (BASELINE configs without their 1e9 .. 1.5e11-row Parquet form).
+  std::string synthetic;
+  uint32_t synth_samples = 0, synth_sites = 0;
+  uint64_t synth_seed = 20240229;
   bool print_schedule = false;          // diagnostic: print the multi-GPU
                                         // schedule as JSON and exit (no GPU used)
   bool help = false;

@@ -49,6 +49,11 @@ def test_flag_validation_messages(tmp_path):
         p = run_cli(*args)
         assert p.returncode == 1, args
         assert "Error: INVALID_ARGUMENT: " in p.stderr and msg in p.stderr, p.stderr
+    for bad in ("--synthetic=abc", "--synthetic=10", "--synthetic=0,5", "--synthetic=4,5,6,7"):
+        p = run_cli(bad, "--output_uri", tmp_path)
+        assert p.returncode == 1 and "Illegal value" in p.stderr and "synthetic" in p.stderr, bad
+    p = run_cli("--synthetic=10,20", "--output_uri", tmp_path, "--dump_bitset", tmp_path / "b")
+    assert p.returncode == 1 and "--dump_bitset needs input tables" in p.stderr
     p = run_cli("--no_such_flag=1")
     assert p.returncode == 1 and "Unknown command line flag" in p.stderr
     p = run_cli("--kin_threshold=abc")
@@ -557,3 +562,33 @@ def test_python_driver_synthetic_mode(tmp_path, oracle, k, shard):
     assert np.array_equal(t.column("kin").to_numpy().view(np.uint32), exp["kin"].view(np.uint32))
     for name in ("ibs0", "ibs1", "ibs2"):
         assert np.array_equal(t.column(name).to_numpy().astype(np.uint32), exp[name])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra,k,shard", [([], 1, 0), (["--num_gpus=1"], 1, 0),
+                                           (["--split_factor=2", "--shard_index=1"], 2, 1),
+                                           (["--split_factor=2", "--shard_index=2", "--num_gpus=1",
+                                             "--multi_gpu_mode=simple"], 2, 2)])
+def test_cli_synthetic_mode(tmp_path, oracle, extra, k, shard):
+    """`cuking --synthetic=N,M,seed`: the C++ host plans the same cohort as
+    cuking_amd.synth.plan_cohort (host/synth_plan.h), the device generator fills
+    the shard's bitset, and the records are the oracle twin's -- through the
+    classic path and through the RCCL path."""
+    import pyarrow.parquet as pq
+    from cuking_amd.synth import plan_cohort
+    n, m, seed, thr = 700, 3000, 5, 0.06
+    out = tmp_path / "out"
+    p = run_cli("--output_uri", out, f"--synthetic={n},{m},{seed}", f"--kin_threshold={thr}",
+                *extra, check=True)
+    assert "Synthesising genotypes on the GPU" in p.stdout
+    cohort = plan_cohort(n, seed)
+    bits = oracle.synth_bitset(seed, cohort.kind, cohort.pa, cohort.pb, 0, n, m)
+    osm = oracle.submatrix(n, k, shard)
+    idx = list(range(osm.i_begin, osm.i_end))
+    if osm.i_begin != osm.j_begin:
+        idx += list(range(osm.j_begin, osm.j_end))
+    exp, _, _ = oracle.compute(osm, np.ascontiguousarray(bits[idx]), thr)
+    assert len(exp) > 0
+    check_output(out / f"part-{shard:05d}.snappy.parquet", exp, [f"S{x:07d}" for x in range(n)])
+    summary = json.loads(p.stdout.strip().splitlines()[-1])
+    assert summary["pack"] == "synthetic" and summary["results"] == len(exp)
