@@ -1116,7 +1116,12 @@ cuking_status cuking_compute_king_rect(
     return fail(CUKING_ERR_INVALID_ARGUMENT, "null result pointer");
   const TiledVariant &v = tiled_variant(effective_variant(ctx, words_per_sample));
   const PlaneGeometry geo = make_geometry(*sm, words_per_sample, v);
-  const TileSpace tiles = make_tiles(geo, v, ctx->band_rows);
+  // Rectangles of a diagonal block contain slots below the diagonal that leave
+  // at once; dealt to the XCDs in contiguous chunks they unbalance the launch
+  // (100k x 100k in 8 staged rectangles: 0.69 s with the XCD order, 0.63 s
+  // round-robin = the single-launch time), so rectangles keep round 1's order:
+  // 17-row bands, workgroup b = slot b.
+  const TileSpace tiles = make_tiles(geo, v, ctx->band_rows ? ctx->band_rows : 17);
   const size_t need = plane_bytes(geo, v.layout);
   const int variant = effective_variant(ctx, words_per_sample);
   if (ctx->planes == nullptr || ctx->planes_bytes < need ||
@@ -1182,7 +1187,7 @@ cuking_status cuking_compute_king_rect(
   a.split_tiles = 0;
   a.split_whole = 0;
   a.split_wgs = ctx->split_wgs;
-  a.xcd_chunk = ctx->xcd_swizzle ? 1u : 0u;
+  a.xcd_chunk = 0;  // (see above)
   a.launch_tiles = 0;
   st = split_scratch_for(ctx, (hipStream_t)stream, &a.split_scratch, &a.split_counters);
   if (st != CUKING_OK) return st;
