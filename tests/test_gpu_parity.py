@@ -882,3 +882,58 @@ def test_staged_rectangles_with_few_emitting_lanes(ctx, counts_mode):
     finally:
         ctx.set_option("split_wgs", 256)
         ctx.set_option("counts_mode", -1)
+
+
+@pytest.mark.parametrize("kernel,variant", KERNELS)
+def test_closed_form_class_counts_on_the_gpu(ctx, kernel, variant):
+    """The 16-class known answers of tests/test_numerics.py straight against the
+    device (no oracle in between): the six sums are read off the chosen
+    multiplicities, kin from exact rational arithmetic rounded twice."""
+    from conftest import kin_exact_two_roundings, pair_from_classes
+    from test_numerics import CLASS_CASES, NAMES
+    select(ctx, kernel, variant)
+    sm = cuking_amd.Submatrix(2)
+    for name in sorted(CLASS_CASES):
+        geno, want = pair_from_classes(CLASS_CASES[name], seed=len(name))
+        bits = cuking_amd.new_host_bitset(sm, geno.shape[1])
+        col, row = np.nonzero(geno >= 0)
+        cuking_amd.pack_host(sm, bits, row, col, geno[col, row])
+        d_bits = ctx.upload_bitset(bits)
+        got = ctx.compute_counts(sm, bits.shape[1], d_bits)[0, 1]
+        assert {n: int(got[n]) for n in NAMES} == want, name
+        if min(want["het_i"], want["het_j"]) > 0:
+            res = ctx.run(sm, bits.shape[1], d_bits, -1e30)
+            exact = kin_exact_two_roundings(want["het_i"], want["het_j"], want["both_het"],
+                                            want["opposing_hom"])
+            assert len(res) == 1 and res["kin"].view(np.uint32)[0] == exact.view(np.uint32), name
+            assert (int(res["ibs0"][0]), int(res["ibs2"][0])) == (
+                want["opposing_hom"], want["concordant_hom"] + want["both_het"])
+            assert int(res["ibs1"][0]) == want["shared"] - int(res["ibs0"][0]) - int(res["ibs2"][0])
+
+
+@pytest.mark.parametrize("kernel,variant", [("tiled", 5), ("tiled", 2), ("stream", 0)])
+def test_wide_pair_with_4opp_beyond_2_24_on_the_gpu(ctx, kernel, variant):
+    """4.6 M sites, 4 x opposing_hom > 2^24: exact sums (float32 accumulation in the
+    matrix-core kernel included) and the documented left-to-right float32 kin."""
+    from conftest import pair_from_classes
+    from test_numerics import NAMES, reference_expression_f32
+    select(ctx, kernel, variant)
+    opp = (1 << 22) + 3
+    mult = [[5, 7, opp // 2, 3], [11, 400_001, 13, 2], [opp - opp // 2, 17, 19, 1],
+            [4, 6, 8, 10]]
+    geno, want = pair_from_classes(mult, seed=5)
+    sm = cuking_amd.Submatrix(2)
+    bits = cuking_amd.new_host_bitset(sm, geno.shape[1])
+    col, row = np.nonzero(geno >= 0)
+    cuking_amd.pack_host(sm, bits, row, col, geno[col, row])
+    d_bits = ctx.upload_bitset(bits)
+    got = ctx.compute_counts(sm, bits.shape[1], d_bits)[0, 1]
+    assert {n: int(got[n]) for n in NAMES} == want
+    for mode in (0, 1):
+        ctx.set_option("counts_mode", mode)
+        res = ctx.run(sm, bits.shape[1], d_bits, -1e30)
+        ref = reference_expression_f32(want["het_i"], want["het_j"], want["both_het"],
+                                       want["opposing_hom"])
+        assert len(res) == 1 and res["kin"].view(np.uint32)[0] == ref.view(np.uint32)
+        assert int(res["ibs0"][0]) == want["opposing_hom"]
+    ctx.set_option("counts_mode", -1)
