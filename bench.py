@@ -103,7 +103,7 @@ def parse_args():
     ap.add_argument("--split-wgs", type=int, default=-1,
                     help="matrix-core kernel: pieces the remainder of a short launch is cut "
                          "into (-1 = library default, one per CU; 0 = never split)")
-    ap.add_argument("--xcd-swizzle", type=int, default=-1, choices=[-1, 0, 1],
+    ap.add_argument("--xcd-swizzle", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="matrix-core kernel: consecutive tiles per XCD (-1 = library default)")
     ap.add_argument("--counts-mode", type=int, default=-1, choices=[-1, 0, 1],
                     help="-1 automatic, 0 lean form (4 sums + recount of emitted pairs), "

@@ -105,7 +105,7 @@ struct cuking_ctx {
   // 0 = by block size (band_rows_for below); tests and tuning runs pin a value.
   uint32_t band_rows = 0;
   int counts_mode = -1;  // -1 auto, 0 lean (4 sums + recount), 1 full (5 sums)
-  int xcd_swizzle = 1;   // matrix-core kernel: consecutive tiles per XCD (king_common.h)
+  int xcd_swizzle = 2;   // matrix-core kernel: XCD-aware order, 0 off / 1 chunks / 2 patches (king_common.h)
 
   // Workspace of the tiled kernel: the k-major planes and the band prefix.
   uint4 *planes = nullptr;
@@ -483,7 +483,7 @@ cuking_status run_tiled(cuking_ctx *ctx, const cuking_submatrix &sm,
   a.split_tiles = 0;
   a.split_whole = 0;
   a.split_wgs = ctx->split_wgs;
-  a.xcd_chunk = ctx->xcd_swizzle ? 1u : 0u;  // (switch; the launch sets the value)
+  a.xcd_chunk = (uint32_t)ctx->xcd_swizzle;  // (switch: 1 chunks, 2 patches; the launch sets the value)
   a.launch_tiles = 0;
   st = split_scratch_for(ctx, stream, &a.split_scratch, &a.split_counters);
   if (st != CUKING_OK) return st;
@@ -702,7 +702,10 @@ cuking_status cuking_ctx_create(int device, cuking_ctx **out) {
     const int k = atoi(v);
     if (k >= 0 && k <= 4096) ctx->split_wgs = (uint32_t)k;
   }
-  if (const char *v = getenv("CUKING_AMD_XCD_SWIZZLE")) ctx->xcd_swizzle = atoi(v) != 0;
+  if (const char *v = getenv("CUKING_AMD_XCD_SWIZZLE")) {
+    const int k = atoi(v);
+    if (k >= 0 && k <= 2) ctx->xcd_swizzle = k;
+  }
   if (const char *v = getenv("CUKING_AMD_BAND_ROWS")) {
     const int k = atoi(v);
     if (k >= 1 && k <= 64) ctx->band_rows = (uint32_t)k;
@@ -767,8 +770,8 @@ cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
     return CUKING_OK;
   }
   if (strcmp(key, "xcd_swizzle") == 0) {
-    if (value < 0 || value > 1)
-      return fail(CUKING_ERR_INVALID_ARGUMENT, "xcd_swizzle outside [0, 1]");
+    if (value < 0 || value > 2)
+      return fail(CUKING_ERR_INVALID_ARGUMENT, "xcd_swizzle outside [0, 2]");
     ctx->xcd_swizzle = (int)value;
     return CUKING_OK;
   }
@@ -1117,10 +1120,11 @@ cuking_status cuking_compute_king_rect(
   const TiledVariant &v = tiled_variant(effective_variant(ctx, words_per_sample));
   const PlaneGeometry geo = make_geometry(*sm, words_per_sample, v);
   // Rectangles of a diagonal block contain slots below the diagonal that leave
-  // at once; dealt to the XCDs in contiguous chunks they unbalance the launch
-  // (100k x 100k in 8 staged rectangles: 0.69 s with the XCD order, 0.63 s
-  // round-robin = the single-launch time), so rectangles keep round 1's order:
-  // 17-row bands, workgroup b = slot b.
+  // at once; one contiguous chunk of the enumeration per XCD then leaves some
+  // XCDs with little real work (100k x 100k in 8 staged rectangles: 0.69 s
+  // against 0.63 s round-robin), so rectangles take the XCD order only in its
+  // patch form (32 consecutive slots per patch, patches dealt round-robin:
+  // 0.66 s), with 17-row bands.
   const TileSpace tiles = make_tiles(geo, v, ctx->band_rows ? ctx->band_rows : 17);
   const size_t need = plane_bytes(geo, v.layout);
   const int variant = effective_variant(ctx, words_per_sample);
@@ -1187,7 +1191,7 @@ cuking_status cuking_compute_king_rect(
   a.split_tiles = 0;
   a.split_whole = 0;
   a.split_wgs = ctx->split_wgs;
-  a.xcd_chunk = 0;  // (see above)
+  a.xcd_chunk = ctx->xcd_swizzle == 2 ? 2u : 0u;  // (see above; patches keep the balance)
   a.launch_tiles = 0;
   st = split_scratch_for(ctx, (hipStream_t)stream, &a.split_scratch, &a.split_counters);
   if (st != CUKING_OK) return st;

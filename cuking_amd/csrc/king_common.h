@@ -128,11 +128,14 @@ struct TiledArgs {
   uint32_t split_whole;
   uint32_t *split_scratch, *split_counters;
   // XCD-aware order (matrix-core kernel, whole-tile launches): workgroups are
-  // dealt round-robin over the 8 XCDs, each with its own L2; with xcd_chunk != 0
-  // workgroup b takes tile (b % 8) * xcd_chunk + b / 8 of the launch's
-  // launch_tiles, so that the workgroups resident on one XCD at a time hold
-  // CONSECUTIVE tiles of the band order (few row/column strips per L2) instead
-  // of every eighth one.
+  // dealt round-robin over the 8 XCDs, each with its own L2.  With xcd_chunk != 0
+  // the workgroups resident on one XCD at a time hold CONSECUTIVE tiles of the
+  // band order (few row/column strips per L2) instead of every eighth one:
+  // xcd_chunk == 1: patches of 32 consecutive tiles, patch p on XCD p % 8
+  // (workgroup b = XCD b % 8, j = b / 8 takes tile ((j / 32) * 8 + b % 8) * 32 +
+  // j % 32); xcd_chunk > 1: one contiguous chunk of xcd_chunk tiles per XCD
+  // (workgroup b takes tile (b % 8) * xcd_chunk + b / 8).  On entry to a launch
+  // function the field is the context's switch (0 off, 1 chunks, 2 patches).
   uint32_t xcd_chunk, launch_tiles;
 };
 

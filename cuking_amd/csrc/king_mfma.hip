@@ -207,8 +207,12 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   const uint64_t whole_units = SPLIT ? (uint64_t)a.split_whole * tile_steps : 0;
   uint32_t bid = blockIdx.x;
   if (!SPLIT && a.xcd_chunk != 0) {
-    bid = (blockIdx.x & 7) * a.xcd_chunk + (blockIdx.x >> 3);
-    if (bid >= a.launch_tiles) return;  // padding of the last chunk (uniform)
+    const uint32_t x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    // xcd_chunk == 1: patches of 32 consecutive tiles dealt round-robin to the
+    // XCDs (XCD x takes patches x, x + 8, ...); otherwise one contiguous chunk
+    // of xcd_chunk tiles per XCD.
+    bid = a.xcd_chunk == 1 ? (((j >> 5) * 8 + x) << 5) + (j & 31) : x * a.xcd_chunk + j;
+    if (bid >= a.launch_tiles) return;  // padding (uniform)
   }
   const bool whole_wg = !SPLIT || blockIdx.x < a.split_whole;
   const uint32_t piece = SPLIT && !whole_wg ? blockIdx.x - a.split_whole : 0;
@@ -804,9 +808,16 @@ hipError_t launch_shape(const TiledArgs &args, uint64_t num_blocks,
     a.tile_begin = args.tile_begin + done;
     uint64_t grid = n;
     if (xcd_order && n >= 64) {
-      a.xcd_chunk = (uint32_t)((n + 7) / 8);
       a.launch_tiles = (uint32_t)n;
-      grid = 8ull * a.xcd_chunk;
+      if (args.xcd_chunk == 2) {  // patches of 32
+        const uint64_t patches = (n + 31) / 32;
+        a.xcd_chunk = 1;
+        grid = 8ull * 32 * ((patches + 7) / 8);
+      } else {
+        a.xcd_chunk = (uint32_t)((n + 7) / 8);
+        if (a.xcd_chunk == 1) a.xcd_chunk = 2;  // (n >= 64: cannot happen; keeps 1 reserved)
+        grid = 8ull * a.xcd_chunk;
+      }
     } else {
       a.xcd_chunk = 0;
     }

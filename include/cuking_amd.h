@@ -185,9 +185,10 @@ cuking_status cuking_ctx_set_kernel(cuking_ctx *ctx, cuking_kernel kernel);
  * (matrix-core variant: short launches cut their remainder of tiles into this
  * many equal pieces, default one per CU, 0 = never), "band_rows"
  * (tile-rows per scheduling band, 1..64, 0 = chosen by block size, the default;
- * env CUKING_AMD_BAND_ROWS), "xcd_swizzle" (matrix-core variant: 1 = the
- * workgroups resident on one XCD hold consecutive tiles of the band order,
- * default; env CUKING_AMD_XCD_SWIZZLE) and
+ * env CUKING_AMD_BAND_ROWS), "xcd_swizzle" (matrix-core variant: the
+ * workgroups resident on one XCD hold consecutive tiles of the band order --
+ * 2 = patches of 32 tiles dealt round-robin to the XCDs (default), 1 = one
+ * contiguous chunk per XCD, 0 = off; env CUKING_AMD_XCD_SWIZZLE) and
  * "counts_mode" (0 = lean: four sums per pair in the main loop, the hom/hom
  * count behind IBS2 recounted only for emitted pairs; 1 = full: all five sums
  * for every pair; -1 = automatic: lean when kin_threshold > c / sqrt(sites), c = 2.05 (1.6 for the VALU variants),

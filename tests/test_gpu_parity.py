@@ -426,7 +426,7 @@ def test_options_round_trip(ctx):
     try:
         assert fresh.get_option("variant") == 5 and fresh.variant_name() == "t128_mfma_fp4"
         assert fresh.get_option("split_wgs") > 0 and fresh.get_option("counts_mode") == -1
-        assert fresh.get_option("xcd_swizzle") == 1 and fresh.get_option("band_rows") == 0
+        assert fresh.get_option("xcd_swizzle") == 2 and fresh.get_option("band_rows") == 0
         for key, value in (("variant", 2), ("band_rows", 9), ("counts_mode", 1), ("split_wgs", 0),
                            ("xcd_swizzle", 0)):
             fresh.set_option(key, value)
@@ -815,7 +815,7 @@ def test_tile_order_options_do_not_change_results(ctx, oracle, split_wgs):
     d_bits = ctx.upload_bitset(bits)
     sm = cuking_amd.Submatrix(n)
     try:
-        for swz in (0, 1):
+        for swz in (0, 1, 2):
             for rows in (0, 1, 3, 5, 17, 64):
                 ctx.set_option("xcd_swizzle", swz)
                 ctx.set_option("band_rows", rows)
@@ -828,7 +828,7 @@ def test_tile_order_options_do_not_change_results(ctx, oracle, split_wgs):
                 merged = cuking_amd.sort_results(np.concatenate(parts))
                 assert merged.tobytes() == exp.tobytes(), (swz, rows, "ranges")
         # an off-diagonal block as well (no triangle in the enumeration)
-        ctx.set_option("xcd_swizzle", 1)
+        ctx.set_option("xcd_swizzle", 2)
         ctx.set_option("band_rows", 0)
         off = cuking_amd.Submatrix(n, 2, 1)
         idx = list(range(off.i_begin, off.i_end)) + list(range(off.j_begin, off.j_end))
@@ -837,7 +837,7 @@ def test_tile_order_options_do_not_change_results(ctx, oracle, split_wgs):
         assert ctx.run(off, bits.shape[1], ctx.upload_bitset(sub), 0.06,
                        max_results=1 << 20).tobytes() == e2.tobytes()
     finally:
-        ctx.set_option("xcd_swizzle", 1)
+        ctx.set_option("xcd_swizzle", 2)
         ctx.set_option("band_rows", 0)
         ctx.set_option("split_wgs", 256)
 

@@ -35,7 +35,7 @@ for case in range(cases):
     exp, _, _ = pyoracle.compute(osm, bits, thr, threads=8)
     sm = cuking_amd.Submatrix(n, k, shard)
     ctx.set_kernel(kernel); ctx.set_option("variant", variant); ctx.set_option("counts_mode", mode)
-    ctx.set_option("xcd_swizzle", int(rng.integers(0, 2)))
+    ctx.set_option("xcd_swizzle", int(rng.integers(0, 3)))
     ctx.set_option("band_rows", int(rng.choice([0, 0, 1, 3, 5, 17])))
     ctx.set_option("split_wgs", int(rng.choice([0, 256, 256])))
     d_bits = (ctx.upload_bitset(bits) if bits.shape[0] else
