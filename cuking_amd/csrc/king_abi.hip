@@ -1252,6 +1252,28 @@ cuking_status cuking_timing_collect(cuking_ctx *ctx, double *king_ms,
   uint64_t na = 0, nb = 0;
   HIP_TRY(ctx->king_timer.collect(&a, &na));
   HIP_TRY(ctx->prepare_timer.collect(&b, &nb));
+#ifdef CUKING_MFMA_STAMPS
+  // diagnostic build: per-phase cycles of the matrix-core kernel's k-step
+  for (auto &e : ctx->split_scratch) {
+    std::vector<unsigned long long> h(1024 * 8);
+    uint32_t *scratch = e.second + mfma_split_counter_bytes(ctx->split_wgs) / sizeof(uint32_t);
+    if (hipMemcpy(h.data(), scratch, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) break;
+    double sum[6] = {0, 0, 0, 0, 0, 0}, steps = 0;
+    int n = 0;
+    for (int b = 0; b < 1024; ++b)
+      if (h[b * 8 + 7] == 0x5354414D50ull) {
+        for (int k = 0; k < 6; ++k) sum[k] += (double)h[b * 8 + k];
+        steps += (double)h[b * 8 + 6];
+        ++n;
+      }
+    if (n)
+      fprintf(stderr,
+              "mfma stamps (%d workgroups): cycles per k-step  f0 %.0f | dma %.0f | f1 %.0f | f2 %.0f "
+              "| sync %.0f | f3 %.0f | total %.0f\n",
+              n, sum[0] / steps, sum[1] / steps, sum[2] / steps, sum[3] / steps, sum[4] / steps,
+              sum[5] / steps, (sum[0] + sum[1] + sum[2] + sum[3] + sum[4] + sum[5]) / steps);
+  }
+#endif
   if (king_ms) *king_ms = a;
   if (king_launches) *king_launches = na;
   if (prepare_ms) *prepare_ms = b;

@@ -142,6 +142,24 @@ __device__ __attribute__((noinline)) void full_emit_call(
     if ((v) > 0) __builtin_amdgcn_sched_group_barrier(0x002, (v), 0);          \
   }
 
+// Diagnostic build (-DCUKING_MFMA_STAMPS, never shipped): where a wavefront's
+// time goes inside a k-step.  One s_memtime per phase boundary (ONE asm statement
+// with its own lgkmcnt(0), MI355X guide, In-kernel stamps), summed per phase and
+// written by wave 0 of the first 1024 workgroups into the (otherwise unused)
+// split scratch; cuking_timing_collect prints the averages.  The stamps cost
+// ~40 cycles each.
+#ifdef CUKING_MFMA_STAMPS
+#define CUKING_STAMP(K)                                                        \
+  {                                                                            \
+    unsigned long long now_;                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
+    stamp_sum[K] += now_ - stamp_last;                                         \
+    stamp_last = now_;                                                         \
+  }
+#else
+#define CUKING_STAMP(K)
+#endif
+
 // Tickets: one per workgroup and pass (the full form makes two).
 __host__ __device__ inline size_t split_counter_bytes(uint32_t wgs) {
   return ((size_t)wgs * 2 * sizeof(uint32_t) + 255) / 256 * 256;
@@ -505,6 +523,10 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     // reload whose first use is inside the loop would put the compiler's
     // s_waitcnt vmcnt(0) there, draining the DMA pipeline in every iteration.
     asm volatile("" : "+v"(row_off), "+v"(col_off), "+v"(lane16));
+#ifdef CUKING_MFMA_STAMPS
+    unsigned long long stamp_sum[6] = {0, 0, 0, 0, 0, 0}, stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
     // One k-step: requests stage STEP + AHEAD into the buffer BACK behind the
     // current one; SYNC = hand stages over (wait + barrier) before the next
     // k-step's LDS reads.
@@ -517,12 +539,14 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       CUKING_MMA16(0, X)                                                       \
       CUKING_PACE(16, 4)                                                       \
       __builtin_amdgcn_sched_barrier(0);                                       \
+      CUKING_STAMP(0)                                                          \
       _Pragma("unroll") for (int r = 0; r < 4; ++r) {                          \
         issue_piece((STEP) + (AHEAD), dbuf, r);                                \
         acc[r >> 1][r & 1][0] =                                                \
             mma<0>(Xa[r >> 1][1], Xb[r & 1][0], acc[r >> 1][r & 1][0]);        \
         __builtin_amdgcn_sched_barrier(0);                                     \
       }                                                                        \
+      CUKING_STAMP(1)                                                          \
       /* f = 1 multiplies (unscaled), f = 2 and the shifted words are built */ \
       CUKING_EXPAND(X, A, B, m4)                                               \
       _Pragma("unroll") for (int b = 0; b < 2; ++b)                            \
@@ -534,21 +558,28 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       CUKING_MMA4(1, Y)                                                        \
       CUKING_PACE(20, 5)                                                       \
       __builtin_amdgcn_sched_barrier(0);                                       \
-      /* f = 2 multiplies, f = 3 is built from the shifted words */            \
+      CUKING_STAMP(2)                                                          \
+      /* f = 2 multiplies, f = 3 is built from the shifted words; the raw words \
+         are dead by now (f = 2 and f = 3 read the shifted copies), so the next \
+         k-step's stage hand-over and LDS reads go here and have this whole     \
+         phase to land before f = 0 of the next k-step is built from them */    \
+      if (SYNC) stage_sync();                                                  \
+      CUKING_STAMP(4)                                                          \
+      CUKING_LOAD_RAW(nbuf)                                                    \
       CUKING_EXPAND(Y, As, Bs, m1)                                             \
       CUKING_MMA16(2, X)                                                       \
       CUKING_MMA4(2, X)                                                        \
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                       \
       CUKING_PACE(16, 4) CUKING_PACE(4, 0)                                     \
       __builtin_amdgcn_sched_barrier(0);                                       \
-      /* f = 3 multiplies; next k-step: hand-over, LDS reads, f = 0 */         \
-      if (SYNC) stage_sync();                                                  \
-      CUKING_LOAD_RAW(nbuf)                                                    \
+      CUKING_STAMP(3)                                                          \
+      /* f = 3 multiplies; f = 0 of the next k-step is built */                \
       CUKING_EXPAND(X, A, B, m1)                                               \
       CUKING_MMA16(3, Y)                                                       \
       CUKING_MMA4(3, Y)                                                        \
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                       \
       CUKING_PACE(4, 0) CUKING_PACE(16, 4)                                     \
       __builtin_amdgcn_sched_barrier(0);                                       \
+      CUKING_STAMP(5)                                                          \
       buf = nbuf;                                                              \
     }
     if constexpr (PAIRED) {
@@ -563,6 +594,15 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
         CUKING_KSTEP(step, true, NSTAGE - 1, 1)
     }
 #undef CUKING_KSTEP
+#ifdef CUKING_MFMA_STAMPS
+    if (!SPLIT && a.split_scratch != nullptr && blockIdx.x < 1024 && threadIdx.x == 0) {
+      unsigned long long *dbg =
+          reinterpret_cast<unsigned long long *>(a.split_scratch) + (size_t)blockIdx.x * 8;
+      for (int k = 0; k < 6; ++k) dbg[k] = stamp_sum[k];
+      dbg[6] = num_steps - 1;
+      dbg[7] = 0x5354414D50ull;  // "STAMP"
+    }
+#endif
     // last k-step: nothing left to fetch
     CUKING_EXPAND(Y, A, B, m2)
     CUKING_MMA16(0, X)
