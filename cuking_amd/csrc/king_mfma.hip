@@ -527,6 +527,74 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     unsigned long long stamp_sum[6] = {0, 0, 0, 0, 0, 0}, stamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
 #endif
+    // Where a k-step's LDS reads of the NEXT k-step go (tools/exp14.sh, one box,
+    // profiles/r02_mfma_stamps.txt): 0 = all eight in front of phase f = 3 (round
+    // 1), 1 = in front of phase f = 2, 2 = phase f = 2, one behind each of its
+    // first eight MFMAs (default), 3 = one per two MFMAs.
+#ifndef CUKING_RD_MODE
+#define CUKING_RD_MODE 2
+#endif
+#if CUKING_RD_MODE == 0
+    // f = 2 multiplies, f = 3 is built from the shifted words
+#define CUKING_PHASE_F2(SYNC)                                                  \
+      CUKING_EXPAND(Y, As, Bs, m1)                                             \
+      CUKING_MMA16(2, X)                                                       \
+      CUKING_MMA4(2, X)                                                        \
+      CUKING_PACE(16, 4) CUKING_PACE(4, 0)                                     \
+      __builtin_amdgcn_sched_barrier(0);
+    // f = 3 multiplies; next k-step: hand-over, LDS reads, f = 0
+#define CUKING_PHASE_F3(SYNC)                                                  \
+      if (SYNC) stage_sync();                                                  \
+      CUKING_STAMP(4)                                                          \
+      CUKING_LOAD_RAW(nbuf)                                                    \
+      CUKING_EXPAND(X, A, B, m1)                                               \
+      CUKING_MMA16(3, Y)                                                       \
+      CUKING_MMA4(3, Y)                                                        \
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                       \
+      CUKING_PACE(4, 0) CUKING_PACE(16, 4)                                     \
+      __builtin_amdgcn_sched_barrier(0);
+#else
+    // The raw words are dead after f = 1 (f = 2 and f = 3 read the shifted
+    // copies): hand-over and LDS reads of the next k-step in phase f = 2.
+#if CUKING_RD_MODE == 1
+#define CUKING_RD_PACE                                                         \
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                       \
+      CUKING_PACE(16, 4) CUKING_PACE(4, 0)
+#elif CUKING_RD_MODE == 2
+#define CUKING_RD_PACE                                                         \
+      _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                     \
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                     \
+      }                                                                        \
+      CUKING_PACE(8, 4) CUKING_PACE(4, 0)
+#else
+#define CUKING_RD_PACE                                                         \
+      _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                     \
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                     \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     \
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                     \
+      }                                                                        \
+      CUKING_PACE(4, 0)
+#endif
+#define CUKING_PHASE_F2(SYNC)                                                  \
+      if (SYNC) stage_sync();                                                  \
+      CUKING_STAMP(4)                                                          \
+      CUKING_LOAD_RAW(nbuf)                                                    \
+      CUKING_EXPAND(Y, As, Bs, m1)                                             \
+      CUKING_MMA16(2, X)                                                       \
+      CUKING_MMA4(2, X)                                                        \
+      CUKING_RD_PACE                                                           \
+      __builtin_amdgcn_sched_barrier(0);
+#define CUKING_PHASE_F3(SYNC)                                                  \
+      CUKING_EXPAND(X, A, B, m1)                                               \
+      CUKING_MMA16(3, Y)                                                       \
+      CUKING_MMA4(3, Y)                                                        \
+      CUKING_PACE(4, 0) CUKING_PACE(16, 4)                                     \
+      __builtin_amdgcn_sched_barrier(0);
+#endif
     // One k-step: requests stage STEP + AHEAD into the buffer BACK behind the
     // current one; SYNC = hand stages over (wait + barrier) before the next
     // k-step's LDS reads.
@@ -559,26 +627,9 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       CUKING_PACE(20, 5)                                                       \
       __builtin_amdgcn_sched_barrier(0);                                       \
       CUKING_STAMP(2)                                                          \
-      /* f = 2 multiplies, f = 3 is built from the shifted words; the raw words \
-         are dead by now (f = 2 and f = 3 read the shifted copies), so the next \
-         k-step's stage hand-over and LDS reads go here and have this whole     \
-         phase to land before f = 0 of the next k-step is built from them */    \
-      if (SYNC) stage_sync();                                                  \
-      CUKING_STAMP(4)                                                          \
-      CUKING_LOAD_RAW(nbuf)                                                    \
-      CUKING_EXPAND(Y, As, Bs, m1)                                             \
-      CUKING_MMA16(2, X)                                                       \
-      CUKING_MMA4(2, X)                                                        \
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                       \
-      CUKING_PACE(16, 4) CUKING_PACE(4, 0)                                     \
-      __builtin_amdgcn_sched_barrier(0);                                       \
+      CUKING_PHASE_F2(SYNC)                                                    \
       CUKING_STAMP(3)                                                          \
-      /* f = 3 multiplies; f = 0 of the next k-step is built */                \
-      CUKING_EXPAND(X, A, B, m1)                                               \
-      CUKING_MMA16(3, Y)                                                       \
-      CUKING_MMA4(3, Y)                                                        \
-      CUKING_PACE(4, 0) CUKING_PACE(16, 4)                                     \
-      __builtin_amdgcn_sched_barrier(0);                                       \
+      CUKING_PHASE_F3(SYNC)                                                    \
       CUKING_STAMP(5)                                                          \
       buf = nbuf;                                                              \
     }
@@ -594,6 +645,8 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
         CUKING_KSTEP(step, true, NSTAGE - 1, 1)
     }
 #undef CUKING_KSTEP
+#undef CUKING_PHASE_F2
+#undef CUKING_PHASE_F3
 #ifdef CUKING_MFMA_STAMPS
     if (!SPLIT && a.split_scratch != nullptr && blockIdx.x < 1024 && threadIdx.x == 0) {
       unsigned long long *dbg =
