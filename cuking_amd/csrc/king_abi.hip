@@ -1252,6 +1252,9 @@ cuking_status cuking_timing_collect(cuking_ctx *ctx, double *king_ms,
   uint64_t na = 0, nb = 0;
   HIP_TRY(ctx->king_timer.collect(&a, &na));
   HIP_TRY(ctx->prepare_timer.collect(&b, &nb));
+#ifdef CUKING_MFMA_TIMELINE
+  mfma_timeline_dump();  // diagnostic build: the last matrix-core launch
+#endif
 #ifdef CUKING_MFMA_STAMPS
   // diagnostic build: per-phase cycles of the matrix-core kernel's k-step
   for (auto &e : ctx->split_scratch) {

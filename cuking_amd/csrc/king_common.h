@@ -189,6 +189,9 @@ hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
 // the counter part alone (the only part that must start out zero).
 size_t mfma_split_scratch_bytes(uint32_t wgs);
 size_t mfma_split_counter_bytes(uint32_t wgs);
+#ifdef CUKING_MFMA_TIMELINE
+void mfma_timeline_dump();  // diagnostic build (king_mfma.hip)
+#endif
 
 // Converts plane-sample tiles [s_tile_begin, s_tile_end) (units of 64 plane
 // samples) of the block.

@@ -34,6 +34,10 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#ifdef CUKING_MFMA_TIMELINE
+#include <algorithm>
+#include <vector>
+#endif
 
 #include "king_common.h"
 #include "king_device.h"
@@ -142,6 +146,25 @@ __device__ __attribute__((noinline)) void full_emit_call(
     if ((v) > 0) __builtin_amdgcn_sched_group_barrier(0x002, (v), 0);          \
   }
 
+// Diagnostic build (-DCUKING_MFMA_TIMELINE, never shipped): when the workgroups
+// of a launch start and finish, and where a piece's time goes (100 MHz
+// s_memrealtime, comparable across the chip).  [workgroup][12]: 0 entry,
+// per segment s (0, 1): 1+5s start, 2+5s loop entered, 3+5s loop done,
+// 4+5s slab / totals done, 5+5s epilogue done, 11 exit.
+#ifdef CUKING_MFMA_TIMELINE
+__device__ unsigned long long *g_timeline;
+constexpr uint32_t kTimelineBlocks = 1u << 16;
+void timeline_arm(uint32_t whole, uint32_t blocks);
+#define CUKING_TL(K)                                                           \
+  if (threadIdx.x == 0 && g_timeline != nullptr && blockIdx.x < kTimelineBlocks) { \
+    unsigned long long t_;                                                     \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    g_timeline[(size_t)blockIdx.x * 12 + (K)] = t_;                            \
+  }
+#else
+#define CUKING_TL(K)
+#endif
+
 // Diagnostic build (-DCUKING_MFMA_STAMPS, never shipped): where a wavefront's
 // time goes inside a k-step.  One s_memtime per phase boundary (ONE asm statement
 // with its own lgkmcnt(0), MI355X guide, In-kernel stamps), summed per phase and
@@ -221,10 +244,14 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   // SPLIT launches: the first split_whole workgroups take one whole tile each,
   // the remaining split_wgs ones cut the units of the last split_tiles tiles
   // into equal pieces (piece index `piece`).
+  CUKING_TL(0)
+  uint32_t tl_seg = 0;  // (timeline build) segment of this workgroup
   const uint64_t units = (uint64_t)a.split_tiles * tile_steps;      // of the cut-up tiles
   const uint64_t whole_units = SPLIT ? (uint64_t)a.split_whole * tile_steps : 0;
   uint32_t bid = blockIdx.x;
-  if (!SPLIT && a.xcd_chunk != 0) {
+  // (SPLIT launches: the whole-tile workgroups in front take the patch order
+  // when their count is a multiple of 8 x 32; the pieces behind them do not)
+  if (a.xcd_chunk != 0 && (!SPLIT || blockIdx.x < a.split_whole)) {
     const uint32_t x = blockIdx.x & 7, j = blockIdx.x >> 3;
     // xcd_chunk == 1: patches of 32 consecutive tiles dealt round-robin to the
     // XCDs (XCD x takes patches x, x + 8, ...); otherwise one contiguous chunk
@@ -277,6 +304,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   tr = __builtin_amdgcn_readfirstlane(tr);
   tc = __builtin_amdgcn_readfirstlane(tc);
 
+  CUKING_TL(1 + 5 * tl_seg)
   const uint4 *g_rows = a.planes + (uint64_t)tr * kTile;
   const uint4 *g_cols = a.planes + a.geo.col_base + (uint64_t)tc * kTile;
 
@@ -633,6 +661,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       CUKING_STAMP(5)                                                          \
       buf = nbuf;                                                              \
     }
+    CUKING_TL(2 + 5 * tl_seg)
     if constexpr (PAIRED) {
       uint32_t step = 0;
       for (; step + 2 < num_steps; step += 2) {
@@ -680,6 +709,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   // workgroup's LDS goes away.
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   if (SPLIT) __syncthreads();  // ... and nobody reads the stages any more
+  CUKING_TL(3 + 5 * tl_seg)
 
   // Full form: the fifth sum stays where the pass in front of the main loop
   // parked it (this lane's 16-byte slots) and is read block by block.
@@ -765,7 +795,11 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     __syncthreads();
     const bool last = *flag != 0;
     __syncthreads();  // the flag word is stage memory again after this
-    if (!last) continue;
+    if (!last) {
+      CUKING_TL(4 + 5 * tl_seg)
+      tl_seg = 1;
+      continue;
+    }
     // Totals: this part is still in registers, the others come from their slabs.
     for (uint32_t w = w_first; w <= w_last; ++w) {
       if (w == piece) continue;
@@ -795,6 +829,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     }
   }
 
+  CUKING_TL(4 + 5 * tl_seg)
   if (ABLATE == 3) {
     float sum = 0.f;
 #pragma unroll
@@ -868,7 +903,10 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     }
   }
   if (SPLIT) __syncthreads();  // LDS is reused by the next piece
+  CUKING_TL(5 + 5 * tl_seg)
+  tl_seg = 1;
   }  // pieces of this workgroup
+  CUKING_TL(11)
 }
 
 template <bool FULL, bool SPLIT, int ABLATE = 0>
@@ -886,8 +924,15 @@ hipError_t launch_shape(const TiledArgs &args, uint64_t num_blocks,
     if (e != hipSuccess) return e;
     attr_set.mark();
   }
-  if (SPLIT) {  // one launch of split_wgs workgroups
-    kernel<<<dim3((uint32_t)num_blocks), dim3(256), lds_bytes, stream>>>(args);
+  if (SPLIT) {  // one launch: split_whole whole tiles + split_wgs pieces
+    TiledArgs a = args;
+    a.xcd_chunk = args.xcd_chunk == 2 && args.split_whole != 0 && args.split_whole % 256 == 0;
+    a.launch_tiles = args.split_whole;
+#ifdef CUKING_MFMA_TIMELINE
+    (void)hipStreamSynchronize(stream);
+    timeline_arm(args.split_whole, (uint32_t)num_blocks);
+#endif
+    kernel<<<dim3((uint32_t)num_blocks), dim3(256), lds_bytes, stream>>>(a);
     return hipGetLastError();
   }
   // (the XCD order pads a launch to a multiple of 8 workgroups)
@@ -914,6 +959,10 @@ hipError_t launch_shape(const TiledArgs &args, uint64_t num_blocks,
     } else {
       a.xcd_chunk = 0;
     }
+#ifdef CUKING_MFMA_TIMELINE
+    (void)hipStreamSynchronize(stream);
+    timeline_arm((uint32_t)grid, (uint32_t)grid);
+#endif
     kernel<<<dim3((uint32_t)grid), dim3(256), lds_bytes, stream>>>(a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -923,6 +972,97 @@ hipError_t launch_shape(const TiledArgs &args, uint64_t num_blocks,
 }
 
 }  // namespace
+
+#ifdef CUKING_MFMA_TIMELINE
+static unsigned long long *g_timeline_host = nullptr;
+static uint32_t g_timeline_whole = 0, g_timeline_blocks = 0;
+namespace {
+void timeline_arm(uint32_t whole, uint32_t blocks) {
+  if (g_timeline_host == nullptr) {
+    if (hipMalloc(&g_timeline_host, (size_t)kTimelineBlocks * 12 * 8) != hipSuccess) return;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &g_timeline_host, sizeof(g_timeline_host));
+  }
+  (void)hipMemset(g_timeline_host, 0, (size_t)kTimelineBlocks * 12 * 8);
+  g_timeline_whole = whole;
+  g_timeline_blocks = blocks < kTimelineBlocks ? blocks : kTimelineBlocks;
+}
+}  // namespace
+void mfma_timeline_dump() {
+  if (g_timeline_host == nullptr || g_timeline_blocks == 0) return;
+  std::vector<unsigned long long> h((size_t)g_timeline_blocks * 12);
+  if (hipMemcpy(h.data(), g_timeline_host, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)
+    return;
+  unsigned long long t0 = ~0ull;
+  for (uint32_t b = 0; b < g_timeline_blocks; ++b)
+    if (h[b * 12] != 0 && h[b * 12] < t0) t0 = h[b * 12];
+  auto us = [&](unsigned long long t) { return t == 0 ? -1.0 : (double)(t - t0) / 100.0; };
+  double whole_end_max = 0, whole_end_min = 1e30, whole_dur = 0;
+  uint32_t nw = 0;
+  for (uint32_t b = 0; b < g_timeline_whole && b < g_timeline_blocks; ++b) {
+    if (h[b * 12 + 11] == 0 || h[b * 12 + 1] == 0) continue;
+    const double e = us(h[b * 12 + 11]);
+    whole_end_max = e > whole_end_max ? e : whole_end_max;
+    whole_dur += e - us(h[b * 12]);
+    ++nw;
+  }
+  // the last 256 whole tiles to finish
+  std::vector<double> ends;
+  for (uint32_t b = 0; b < g_timeline_whole && b < g_timeline_blocks; ++b)
+    if (h[b * 12 + 11] != 0 && h[b * 12 + 1] != 0) ends.push_back(us(h[b * 12 + 11]));
+  std::sort(ends.begin(), ends.end());
+  if (ends.size() >= 256) whole_end_min = ends[ends.size() - 256];
+  fprintf(stderr, "timeline: %u whole tiles, mean %.1f us each; the last 256 end %.1f .. %.1f us\n",
+          nw, nw ? whole_dur / nw : 0.0, whole_end_min, whole_end_max);
+  double st_min = 1e30, st_max = 0, en_min = 1e30, en_max = 0;
+  double seg[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  uint32_t nseg[2] = {0, 0}, np = 0;
+  for (uint32_t b = g_timeline_whole; b < g_timeline_blocks; ++b) {
+    if (h[b * 12] == 0) continue;
+    const double st = us(h[b * 12]), en = us(h[b * 12 + 11]);
+    st_min = st < st_min ? st : st_min; st_max = st > st_max ? st : st_max;
+    en_min = en < en_min ? en : en_min; en_max = en > en_max ? en : en_max;
+    ++np;
+    for (int sgm = 0; sgm < 2; ++sgm) {
+      const unsigned long long *q = &h[b * 12 + 1 + 5 * sgm];
+      if (q[0] == 0 || q[2] == 0) continue;
+      ++nseg[sgm];
+      seg[sgm][0] += us(q[1]) - us(q[0]);
+      seg[sgm][1] += us(q[2]) - us(q[1]);
+      if (q[3] != 0) seg[sgm][2] += us(q[3]) - us(q[2]);
+      if (q[4] != 0 && q[3] != 0) seg[sgm][3] += us(q[4]) - us(q[3]);
+    }
+  }
+  if (np != 0) {
+    fprintf(stderr, "timeline: %u pieces start %.1f .. %.1f us, end %.1f .. %.1f us\n", np, st_min,
+            st_max, en_min, en_max);
+    for (int sgm = 0; sgm < 2; ++sgm)
+      if (nseg[sgm])
+        fprintf(stderr,
+                "timeline: segment %d of a piece (%u): fill %.1f | loop %.1f | slab+ticket/totals %.1f "
+                "| epilogue %.1f us (sums over pieces / pieces with the segment)\n",
+                sgm, nseg[sgm], seg[sgm][0] / nseg[sgm], seg[sgm][1] / nseg[sgm],
+                seg[sgm][2] / nseg[sgm], seg[sgm][3] / nseg[sgm]);
+  }
+  // the pieces that finish last, stamp by stamp
+  std::vector<std::pair<double, uint32_t>> order;
+  for (uint32_t b = g_timeline_whole; b < g_timeline_blocks; ++b)
+    if (h[b * 12] != 0) order.emplace_back(us(h[b * 12 + 11]), b);
+  std::sort(order.begin(), order.end());
+  for (size_t k = order.size() > 6 ? order.size() - 6 : 0; k < order.size(); ++k) {
+    const uint32_t b = order[k].second;
+    fprintf(stderr, "timeline: piece %u:", b - g_timeline_whole);
+    for (int q = 0; q < 12; ++q) fprintf(stderr, " %.1f", us(h[b * 12 + q]));
+    fprintf(stderr, "\n");
+  }
+  for (size_t k = 0; k < 3 && k < order.size(); ++k) {
+    const uint32_t b = order[k].second;
+    fprintf(stderr, "timeline: (early) piece %u:", b - g_timeline_whole);
+    for (int q = 0; q < 12; ++q) fprintf(stderr, " %.1f", us(h[b * 12 + q]));
+    fprintf(stderr, "\n");
+  }
+  g_timeline_blocks = 0;
+}
+#endif
 
 size_t mfma_split_scratch_bytes(uint32_t wgs) {
   // one counter per tile (padded to 16 bytes), then two slabs of five sums per
@@ -946,18 +1086,24 @@ hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
   // Whole rounds of one tile per workgroup, then the remainder (the tiles that
   // would leave most CUs idle for a whole tile time) cut into equal pieces of
   // k-steps over all CUs, in the SAME launch: a CU that finishes its last
-  // whole tile goes straight on to a piece.  Only for launches of fewer than
-  // 8 tiles per CU (small blocks, the rectangles of the staged multi-GPU
-  // schedule): 36 tiles 0.57 -> 0.25 ms, 300 tiles 1.26 -> 0.91 ms, 820 tiles
-  // 2.40 -> 2.15 ms, 2016 tiles 4.54 -> 4.56 ms; with more rounds the
-  // dispatcher's own back-filling leaves a tail of under 3 % and the pieces'
-  // overhead (slabs, extra prologues) costs more than it saves (3160 tiles:
-  // 6.94 -> 7.04 ms).
+  // whole tile goes straight on to a piece.  For launches of fewer than
+  // CUKING_SPLIT_ROUNDS tiles per CU: 36 tiles 0.57 -> 0.25 ms, 300 tiles
+  // 1.26 -> 0.91 ms, 820 tiles 2.40 -> 2.15 ms; configs[1] (3160 tiles = 12.3
+  // rounds, the dispatcher's back-filling does not hide the 13th: time follows
+  // ceil(rounds), tools/exp15.sh) 6.93 -> 6.75 ms and 7.12 -> 6.84 ms on two
+  // boxes.  A piece costs ~30 us per tile it touches (slab, ticket) and the
+  // pieces end as far apart as the whole tiles before them did (~0.3 ms after
+  // 12 rounds), which is what is left of the ideal 0.66 x 0.53 ms
+  // (profiles/r02_tail.txt); beyond 64 rounds the gain is under 1 %.
   const uint32_t wgs = args.split_wgs;
   const uint32_t tile_steps = args.geo.k_words / 8;
   uint64_t whole = num_tiles;
   uint32_t rest = 0;
-  if (wgs != 0 && args.split_scratch != nullptr && num_tiles < 8ull * wgs) {
+#ifndef CUKING_SPLIT_ROUNDS
+#define CUKING_SPLIT_ROUNDS 64
+#endif
+  if (wgs != 0 && args.split_scratch != nullptr &&
+      num_tiles < (uint64_t)CUKING_SPLIT_ROUNDS * wgs) {
     // under two tiles per CU everything goes out as pieces (300 tiles:
     // 0.98 -> 0.91 ms); otherwise the remainder after whole rounds
     rest = num_tiles < 2ull * wgs ? (uint32_t)num_tiles : (uint32_t)(num_tiles % wgs);
