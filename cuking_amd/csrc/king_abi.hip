@@ -106,6 +106,7 @@ struct cuking_ctx {
   uint32_t band_rows = 0;
   int counts_mode = -1;  // -1 auto, 0 lean (4 sums + recount), 1 full (5 sums)
   int xcd_swizzle = 2;   // matrix-core kernel: XCD-aware order, 0 off / 1 chunks / 2 patches (king_common.h)
+  uint32_t dyn_tail_tiles = 16384;  // launches of at least this many tiles get a dynamic tail; 0 = never
 
   // Workspace of the tiled kernel: the k-major planes and the band prefix.
   uint4 *planes = nullptr;
@@ -485,6 +486,8 @@ cuking_status run_tiled(cuking_ctx *ctx, const cuking_submatrix &sm,
   a.split_wgs = ctx->split_wgs;
   a.xcd_chunk = (uint32_t)ctx->xcd_swizzle;  // (switch: 1 chunks, 2 patches; the launch sets the value)
   a.launch_tiles = 0;
+  a.dyn_tiles = ctx->dyn_tail_tiles;  // (threshold; the launch sets the count)
+  a.dyn_wgs = 0;
   st = split_scratch_for(ctx, stream, &a.split_scratch, &a.split_counters);
   if (st != CUKING_OK) return st;
 
@@ -706,6 +709,10 @@ cuking_status cuking_ctx_create(int device, cuking_ctx **out) {
     const int k = atoi(v);
     if (k >= 0 && k <= 2) ctx->xcd_swizzle = k;
   }
+  if (const char *v = getenv("CUKING_AMD_DYN_TAIL_TILES")) {
+    const long long k = atoll(v);
+    if (k >= 0 && k <= 0x7FFFFFFF) ctx->dyn_tail_tiles = (uint32_t)k;
+  }
   if (const char *v = getenv("CUKING_AMD_BAND_ROWS")) {
     const int k = atoi(v);
     if (k >= 1 && k <= 64) ctx->band_rows = (uint32_t)k;
@@ -767,6 +774,12 @@ cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
   if (strcmp(key, "max_launch_blocks") == 0) {  // test hook, process-wide
     if (value < 0) return fail(CUKING_ERR_INVALID_ARGUMENT, "negative block cap");
     set_max_blocks_per_launch((uint64_t)value);
+    return CUKING_OK;
+  }
+  if (strcmp(key, "dyn_tail_tiles") == 0) {  // 0 = never; tests lower it
+    if (value < 0 || value > 0x7FFFFFFF)
+      return fail(CUKING_ERR_INVALID_ARGUMENT, "dyn_tail_tiles outside [0, 2^31)");
+    ctx->dyn_tail_tiles = (uint32_t)value;
     return CUKING_OK;
   }
   if (strcmp(key, "xcd_swizzle") == 0) {
@@ -997,6 +1010,7 @@ cuking_status cuking_ctx_get_option(const cuking_ctx *ctx, const char *key,
   else if (strcmp(key, "band_rows") == 0) *value = ctx->band_rows;
   else if (strcmp(key, "counts_mode") == 0) *value = ctx->counts_mode;
   else if (strcmp(key, "xcd_swizzle") == 0) *value = ctx->xcd_swizzle;
+  else if (strcmp(key, "dyn_tail_tiles") == 0) *value = ctx->dyn_tail_tiles;
   else return fail(CUKING_ERR_INVALID_ARGUMENT, "unknown option %s", key);
   return CUKING_OK;
 }
@@ -1193,6 +1207,8 @@ cuking_status cuking_compute_king_rect(
   a.split_wgs = ctx->split_wgs;
   a.xcd_chunk = ctx->xcd_swizzle == 2 ? 2u : 0u;  // (see above; patches keep the balance)
   a.launch_tiles = 0;
+  a.dyn_tiles = 0;  // (rectangles: no dynamic tail)
+  a.dyn_wgs = 0;
   st = split_scratch_for(ctx, (hipStream_t)stream, &a.split_scratch, &a.split_counters);
   if (st != CUKING_OK) return st;
   EventPair *ev = nullptr;

@@ -137,6 +137,17 @@ struct TiledArgs {
   // (workgroup b takes tile (b % 8) * xcd_chunk + b / 8).  On entry to a launch
   // function the field is the context's switch (0 off, 1 chunks, 2 patches).
   uint32_t xcd_chunk, launch_tiles;
+  // Dynamic tail (matrix-core kernel, whole-tile launches of many rounds): the
+  // XCDs of an MI355X run this kernel at rates 2-3 % apart and a launch's
+  // workgroups are dealt to them statically, so the launch would end when the
+  // slowest XCD does.  The last dyn_tiles tiles of a launch are therefore not
+  // tied to a workgroup index: dyn_wgs (> dyn_tiles) workgroups behind the
+  // launch_tiles statically mapped ones each take the next tile from a counter
+  // (in split_counters, zero between launches) or leave at once when none is
+  // left -- an XCD that gets through its static share early takes more of them.
+  // On entry to a launch function dyn_tiles is the context's threshold: launches
+  // of at least that many tiles get a dynamic tail (0 = never).
+  uint32_t dyn_tiles, dyn_wgs;
 };
 
 // Bytes of the plane workspace for a geometry.

@@ -153,7 +153,7 @@ __device__ __attribute__((noinline)) void full_emit_call(
 // 4+5s slab / totals done, 5+5s epilogue done, 11 exit.
 #ifdef CUKING_MFMA_TIMELINE
 __device__ unsigned long long *g_timeline;
-constexpr uint32_t kTimelineBlocks = 1u << 16;
+constexpr uint32_t kTimelineBlocks = 1u << 19;
 void timeline_arm(uint32_t whole, uint32_t blocks);
 #define CUKING_TL(K)                                                           \
   if (threadIdx.x == 0 && g_timeline != nullptr && blockIdx.x < kTimelineBlocks) { \
@@ -185,7 +185,11 @@ void timeline_arm(uint32_t whole, uint32_t blocks);
 
 // Tickets: one per workgroup and pass (the full form makes two).
 __host__ __device__ inline size_t split_counter_bytes(uint32_t wgs) {
-  return ((size_t)wgs * 2 * sizeof(uint32_t) + 255) / 256 * 256;
+  return ((size_t)wgs * 2 * sizeof(uint32_t) + 255) / 256 * 256 + 256;
+}
+// ... and, in the last 256 bytes, the tile counter of a launch's dynamic tail.
+__host__ __device__ inline size_t dyn_counter_index(uint32_t wgs) {
+  return (split_counter_bytes(wgs) - 256) / sizeof(uint32_t);
 }
 
 // First work unit of split workgroup w: floor(w * units / wgs).
@@ -245,10 +249,29 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   // the remaining split_wgs ones cut the units of the last split_tiles tiles
   // into equal pieces (piece index `piece`).
   CUKING_TL(0)
-  uint32_t tl_seg = 0;  // (timeline build) segment of this workgroup
+  [[maybe_unused]] uint32_t tl_seg = 0;  // (timeline build) segment of this workgroup
   const uint64_t units = (uint64_t)a.split_tiles * tile_steps;      // of the cut-up tiles
   const uint64_t whole_units = SPLIT ? (uint64_t)a.split_whole * tile_steps : 0;
   uint32_t bid = blockIdx.x;
+  if (!SPLIT && a.dyn_tiles != 0 && blockIdx.x >= a.launch_tiles) {
+    // dynamic tail (king_common.h): the next tile nobody has taken yet
+    uint32_t *slot = reinterpret_cast<uint32_t *>(lds);
+    if (threadIdx.x == 0) {
+      uint32_t *counter = a.split_counters + dyn_counter_index(a.split_wgs);
+      const uint32_t t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+      // every workgroup of the tail asks exactly once: the last one to ask
+      // leaves the counter ready for the next launch
+      if (t == a.dyn_wgs - 1)
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *slot = t;
+    }
+    __syncthreads();
+    const uint32_t t = __builtin_amdgcn_readfirstlane(*slot);
+    __syncthreads();  // the word is stage memory from here on
+    if (t >= a.dyn_tiles) return;  // uniform
+    bid = a.launch_tiles + t;
+  } else
   // (SPLIT launches: the whole-tile workgroups in front take the patch order
   // when their count is a multiple of 8 x 32; the pieces behind them do not)
   if (a.xcd_chunk != 0 && (!SPLIT || blockIdx.x < a.split_whole)) {
@@ -256,7 +279,11 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     // xcd_chunk == 1: patches of 32 consecutive tiles dealt round-robin to the
     // XCDs (XCD x takes patches x, x + 8, ...); otherwise one contiguous chunk
     // of xcd_chunk tiles per XCD.
-    bid = a.xcd_chunk == 1 ? (((j >> 5) * 8 + x) << 5) + (j & 31) : x * a.xcd_chunk + j;
+#ifndef CUKING_XCD_XOR
+#define CUKING_XCD_XOR 0  // (experiment: which patches an XCD takes, profiles/r02_tail.txt)
+#endif
+    bid = a.xcd_chunk == 1 ? (((j >> 5) * 8 + (x ^ CUKING_XCD_XOR)) << 5) + (j & 31)
+                           : x * a.xcd_chunk + j;
     if (bid >= a.launch_tiles) return;  // padding (uniform)
   }
   const bool whole_wg = !SPLIT || blockIdx.x < a.split_whole;
@@ -928,6 +955,7 @@ hipError_t launch_shape(const TiledArgs &args, uint64_t num_blocks,
     TiledArgs a = args;
     a.xcd_chunk = args.xcd_chunk == 2 && args.split_whole != 0 && args.split_whole % 256 == 0;
     a.launch_tiles = args.split_whole;
+    a.dyn_tiles = a.dyn_wgs = 0;
 #ifdef CUKING_MFMA_TIMELINE
     (void)hipStreamSynchronize(stream);
     timeline_arm(args.split_whole, (uint32_t)num_blocks);
@@ -939,13 +967,34 @@ hipError_t launch_shape(const TiledArgs &args, uint64_t num_blocks,
   uint64_t cap = max_blocks_per_launch(256);
   const bool xcd_order = args.xcd_chunk != 0 && cap >= 64;
   if (xcd_order) cap &= ~7ull;
+  // Dynamic tail: the last ~6 % of a launch's tiles (more than twice the 2-3 %
+  // by which the XCDs differ), behind a statically mapped part of whole
+  // patch rounds; half as many workgroups again as tiles, so that no XCD runs
+  // out of workgroups before the tiles run out.
+  const bool dyn_ok = args.dyn_tiles != 0 && args.xcd_chunk == 2 && xcd_order &&
+                      args.split_counters != nullptr && args.rect_rows == 0;
+  const uint64_t dyn_min = args.dyn_tiles;
   uint64_t done = 0;
   while (done < num_blocks) {
-    const uint64_t n = (num_blocks - done < cap) ? num_blocks - done : cap;
+    uint64_t n = (num_blocks - done < cap) ? num_blocks - done : cap;
+    uint64_t dyn = 0, dyn_wgs = 0;
+    if (dyn_ok && n >= dyn_min && n >= 512) {
+      if (n + n / 8 > cap) n = cap - cap / 8;  // room for the tail's spare workgroups
+      const uint64_t fixed = (n - n / 16) / 256 * 256;
+      dyn = n - fixed;
+      dyn_wgs = dyn + dyn / 2;
+      if (fixed + dyn_wgs > cap) dyn = dyn_wgs = 0;  // (tiny block limits: test hook)
+    }
     TiledArgs a = args;
     a.tile_begin = args.tile_begin + done;
+    a.dyn_tiles = (uint32_t)dyn;
+    a.dyn_wgs = (uint32_t)dyn_wgs;
     uint64_t grid = n;
-    if (xcd_order && n >= 64) {
+    if (dyn != 0) {
+      a.launch_tiles = (uint32_t)(n - dyn);  // whole rounds of patches
+      a.xcd_chunk = 1;
+      grid = n - dyn + dyn_wgs;
+    } else if (xcd_order && n >= 64) {
       a.launch_tiles = (uint32_t)n;
       if (args.xcd_chunk == 2) {  // patches of 32
         const uint64_t patches = (n + 31) / 32;
@@ -1013,6 +1062,20 @@ void mfma_timeline_dump() {
   if (ends.size() >= 256) whole_end_min = ends[ends.size() - 256];
   fprintf(stderr, "timeline: %u whole tiles, mean %.1f us each; the last 256 end %.1f .. %.1f us\n",
           nw, nw ? whole_dur / nw : 0.0, whole_end_min, whole_end_max);
+  {  // per XCD (workgroup b runs on XCD b % 8): tiles, mean tile time, last exit
+    double dur[8] = {}, last[8] = {};
+    uint32_t cnt[8] = {};
+    for (uint32_t b = 0; b < g_timeline_whole && b < g_timeline_blocks; ++b) {
+      if (h[b * 12 + 11] == 0 || h[b * 12 + 1] == 0) continue;
+      const double e = us(h[b * 12 + 11]);
+      dur[b & 7] += e - us(h[b * 12]);
+      ++cnt[b & 7];
+      last[b & 7] = e > last[b & 7] ? e : last[b & 7];
+    }
+    for (int x = 0; x < 8; ++x)
+      fprintf(stderr, "timeline: XCD %d: %u tiles, mean %.1f us, last exit %.1f us\n", x, cnt[x],
+              cnt[x] ? dur[x] / cnt[x] : 0.0, last[x]);
+  }
   double st_min = 1e30, st_max = 0, en_min = 1e30, en_max = 0;
   double seg[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   uint32_t nseg[2] = {0, 0}, np = 0;
@@ -1042,6 +1105,20 @@ void mfma_timeline_dump() {
                 "| epilogue %.1f us (sums over pieces / pieces with the segment)\n",
                 sgm, nseg[sgm], seg[sgm][0] / nseg[sgm], seg[sgm][1] / nseg[sgm],
                 seg[sgm][2] / nseg[sgm], seg[sgm][3] / nseg[sgm]);
+  }
+  // start of every 16th piece (dispatch order) and the sorted starts
+  {
+    std::vector<double> st;
+    fprintf(stderr, "timeline: piece starts by index (every 16th):");
+    for (uint32_t b = g_timeline_whole; b < g_timeline_blocks; ++b) {
+      if (h[b * 12] == 0) continue;
+      st.push_back(us(h[b * 12]));
+      if ((b - g_timeline_whole) % 16 == 0) fprintf(stderr, " %.0f", us(h[b * 12]));
+    }
+    std::sort(st.begin(), st.end());
+    fprintf(stderr, "\ntimeline: piece starts sorted (every 16th):");
+    for (size_t k = 0; k < st.size(); k += 16) fprintf(stderr, " %.0f", st[k]);
+    fprintf(stderr, "\n");
   }
   // the pieces that finish last, stamp by stamp
   std::vector<std::pair<double, uint32_t>> order;

@@ -188,7 +188,11 @@ cuking_status cuking_ctx_set_kernel(cuking_ctx *ctx, cuking_kernel kernel);
  * env CUKING_AMD_BAND_ROWS), "xcd_swizzle" (matrix-core variant: the
  * workgroups resident on one XCD hold consecutive tiles of the band order --
  * 2 = patches of 32 tiles dealt round-robin to the XCDs (default), 1 = one
- * contiguous chunk per XCD, 0 = off; env CUKING_AMD_XCD_SWIZZLE) and
+ * contiguous chunk per XCD, 0 = off; env CUKING_AMD_XCD_SWIZZLE),
+ * "dyn_tail_tiles" (matrix-core variant: launches of at least this many tiles
+ * hand their last ~6 % out through a counter instead of by workgroup index, so
+ * that the XCDs, which differ by 2-3 %, finish together; default 16384, 0 =
+ * never; env CUKING_AMD_DYN_TAIL_TILES) and
  * "counts_mode" (0 = lean: four sums per pair in the main loop, the hom/hom
  * count behind IBS2 recounted only for emitted pairs; 1 = full: all five sums
  * for every pair; -1 = automatic: lean when kin_threshold > c / sqrt(sites), c = 2.05 (1.6 for the VALU variants),
@@ -196,8 +200,8 @@ cuking_status cuking_ctx_set_kernel(cuking_ctx *ctx, cuking_kernel kernel);
  * not depend on any of them. */
 cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
                                     int64_t value);
-/* Current value of "variant", "split_wgs", "band_rows", "xcd_swizzle" or
- * "counts_mode". */
+/* Current value of "variant", "split_wgs", "band_rows", "xcd_swizzle",
+ * "dyn_tail_tiles" or "counts_mode". */
 cuking_status cuking_ctx_get_option(const cuking_ctx *ctx, const char *key,
                                     int64_t *value);
 int cuking_num_variants(void);

@@ -842,6 +842,49 @@ def test_tile_order_options_do_not_change_results(ctx, oracle, split_wgs):
         ctx.set_option("split_wgs", 256)
 
 
+def test_dynamic_tail_of_a_launch(ctx, oracle):
+    """Launches of many rounds hand their last tiles out through a counter
+    (king_common.h, dyn_tiles): the same records as the static order, launch after
+    launch (the counter returns to zero), in both forms, with the launch cut into
+    several by the block limit, and for tile sub-ranges."""
+    rng = np.random.default_rng(77)
+    n, m = 6000, 500                       # 47 tile rows: 1128 tiles
+    geno = random_genotypes(rng, n, m, missing=0.03)
+    geno[n - 1], geno[3000], geno[5900] = geno[7], geno[130], geno[5899]
+    bits = oracle.bitset_from_genotypes(geno)
+    exp, _, _ = oracle.compute(oracle.submatrix(n), bits, 0.07, threads=16)
+    assert len(exp) >= 3
+    d_bits = ctx.upload_bitset(bits)
+    sm = cuking_amd.Submatrix(n)
+    try:
+        ctx.set_option("split_wgs", 4)     # 1128 tiles = 282 rounds of 4: no remainder pieces
+        ctx.set_option("dyn_tail_tiles", 1)
+        assert ctx.get_option("dyn_tail_tiles") == 1
+        for mode in (0, 1):
+            ctx.set_option("counts_mode", mode)
+            for rep in range(3):
+                got = ctx.run(sm, bits.shape[1], d_bits, 0.07, max_results=1 << 20)
+                assert got.tobytes() == exp.tobytes(), (mode, rep)
+        ctx.set_option("counts_mode", -1)
+        tiles = ctx.num_tiles(sm)
+        parts = [ctx.run(sm, bits.shape[1], d_bits, 0.07, max_results=1 << 20, tile_range=r,
+                         sort=False) for r in ((0, 520), (520, 521), (521, tiles))]   # 520 / 1 / 607 tiles
+        merged = cuking_amd.sort_results(np.concatenate(parts))
+        assert merged.tobytes() == exp.tobytes()
+        ctx.set_option("max_launch_blocks", 700)   # two launches, each with its own tail
+        got = ctx.run(sm, bits.shape[1], d_bits, 0.07, max_results=1 << 20)
+        assert got.tobytes() == exp.tobytes()
+        ctx.set_option("max_launch_blocks", 0)
+        ctx.set_option("dyn_tail_tiles", 0)        # and switched off
+        got = ctx.run(sm, bits.shape[1], d_bits, 0.07, max_results=1 << 20)
+        assert got.tobytes() == exp.tobytes()
+    finally:
+        ctx.set_option("max_launch_blocks", 0)
+        ctx.set_option("counts_mode", -1)
+        ctx.set_option("split_wgs", 256)
+        ctx.set_option("dyn_tail_tiles", 16384)
+
+
 @pytest.mark.parametrize("counts_mode", [0, 1])
 def test_staged_rectangles_with_few_emitting_lanes(ctx, counts_mode):
     """Staged rectangles (invalid tile slots below the diagonal) x remainder split
