@@ -253,8 +253,10 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   const uint64_t units = (uint64_t)a.split_tiles * tile_steps;      // of the cut-up tiles
   const uint64_t whole_units = SPLIT ? (uint64_t)a.split_whole * tile_steps : 0;
   uint32_t bid = blockIdx.x;
-  if (!SPLIT && a.dyn_tiles != 0 && blockIdx.x >= a.launch_tiles) {
-    // dynamic tail (king_common.h): the next tile nobody has taken yet
+  uint32_t piece = 0;
+  if (a.dyn_tiles != 0 && blockIdx.x >= a.launch_tiles) {
+    // dynamic tail (king_common.h): the next tile (SPLIT: the next piece of the
+    // remainder) nobody has taken yet
     uint32_t *slot = reinterpret_cast<uint32_t *>(lds);
     if (threadIdx.x == 0) {
       uint32_t *counter = a.split_counters + dyn_counter_index(a.split_wgs);
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     const uint32_t t = __builtin_amdgcn_readfirstlane(*slot);
     __syncthreads();  // the word is stage memory from here on
     if (t >= a.dyn_tiles) return;  // uniform
-    bid = a.launch_tiles + t;
+    if (SPLIT) piece = t; else bid = a.launch_tiles + t;
   } else
   // (SPLIT launches: the whole-tile workgroups in front take the patch order
   // when their count is a multiple of 8 x 32; the pieces behind them do not)
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     if (bid >= a.launch_tiles) return;  // padding (uniform)
   }
   const bool whole_wg = !SPLIT || blockIdx.x < a.split_whole;
-  const uint32_t piece = SPLIT && !whole_wg ? blockIdx.x - a.split_whole : 0;
+
   uint64_t unit_lo = whole_wg ? (uint64_t)bid * tile_steps
                               : whole_units + split_bound(piece, units, a.split_wgs);
   uint64_t unit_hi = whole_wg ? unit_lo + tile_steps
@@ -955,7 +957,15 @@ hipError_t launch_shape(const TiledArgs &args, uint64_t num_blocks,
     TiledArgs a = args;
     a.xcd_chunk = args.xcd_chunk == 2 && args.split_whole != 0 && args.split_whole % 256 == 0;
     a.launch_tiles = args.split_whole;
-    a.dyn_tiles = a.dyn_wgs = 0;
+    // the pieces are taken from the counter as well (an XCD that finishes its
+    // whole tiles early takes more of them): half as many workgroups again
+    if ((args.split_wgs & 0x80000000u) == 0) {
+      a.dyn_tiles = args.split_wgs;
+      a.dyn_wgs = args.split_wgs + args.split_wgs / 2;
+      num_blocks = (uint64_t)args.split_whole + a.dyn_wgs;
+    } else {
+      a.dyn_tiles = a.dyn_wgs = 0;  // (tuning builds: persistent workgroups)
+    }
 #ifdef CUKING_MFMA_TIMELINE
     (void)hipStreamSynchronize(stream);
     timeline_arm(args.split_whole, (uint32_t)num_blocks);
@@ -1222,7 +1232,7 @@ hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
   // Anything beyond one launch's block limit goes out whole before it.
   const uint64_t cap = max_blocks_per_launch(256);
   uint64_t head = whole;
-  if (cap <= wgs) {
+  if (cap <= wgs + wgs / 2) {
     // (test hook: a block limit below the piece count) whole tiles on their
     // own, in as many launches as it takes, then the pieces
     if (head != 0) {
@@ -1232,8 +1242,8 @@ hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
     }
     a.tile_begin = args.tile_begin + head;
     head = 0;
-  } else if (head + wgs > cap) {
-    const uint64_t first = head + wgs - cap;
+  } else if (head + wgs + wgs / 2 > cap) {  // (the pieces' launch has wgs / 2 spare workgroups)
+    const uint64_t first = head + wgs + wgs / 2 - cap;
     const hipError_t e = full ? launch_shape<true, false>(a, first, lds_bytes, stream)
                               : launch_shape<false, false>(a, first, lds_bytes, stream);
     if (e != hipSuccess) return e;
