@@ -1207,7 +1207,7 @@ cuking_status cuking_compute_king_rect(
   a.split_wgs = ctx->split_wgs;
   a.xcd_chunk = ctx->xcd_swizzle == 2 ? 2u : 0u;  // (see above; patches keep the balance)
   a.launch_tiles = 0;
-  a.dyn_tiles = 0;  // (rectangles: no dynamic tail)
+  a.dyn_tiles = ctx->dyn_tail_tiles;
   a.dyn_wgs = 0;
   st = split_scratch_for(ctx, (hipStream_t)stream, &a.split_scratch, &a.split_counters);
   if (st != CUKING_OK) return st;

@@ -982,7 +982,7 @@ hipError_t launch_shape(const TiledArgs &args, uint64_t num_blocks,
   // patch rounds; half as many workgroups again as tiles, so that no XCD runs
   // out of workgroups before the tiles run out.
   const bool dyn_ok = args.dyn_tiles != 0 && args.xcd_chunk == 2 && xcd_order &&
-                      args.split_counters != nullptr && args.rect_rows == 0;
+                      args.split_counters != nullptr;
   const uint64_t dyn_min = args.dyn_tiles;
   uint64_t done = 0;
   while (done < num_blocks) {

@@ -871,6 +871,27 @@ def test_dynamic_tail_of_a_launch(ctx, oracle):
                          sort=False) for r in ((0, 520), (520, 521), (521, tiles))]   # 520 / 1 / 607 tiles
         merged = cuking_amd.sort_results(np.concatenate(parts))
         assert merged.tobytes() == exp.tobytes()
+        # the staged multi-GPU rectangles (side streams, one counter each) as well
+        import torch
+        from cuking_amd.dist import GpuStagedOps, staged_schedule
+        src = torch.from_numpy(bits.view(np.int64))
+        parts = []
+        for rank in range(2):
+            d_recv = torch.zeros((n, bits.shape[1]), dtype=torch.int64, device="cuda:0")
+            ops = GpuStagedOps(ctx, sm, bits.shape[1], d_recv, 0.07, 1 << 20)
+            ops.begin()
+            for (c0, c1), rect in staged_schedule(n, ctx.tile_samples(), 2, rank, 2):
+                d_recv[c0:c1].copy_(src[c0:c1])
+                if rect is None:
+                    continue
+                ops.prepare(c0, c1)
+                ops.compute_rect(*rect)
+            res, count, ovf = ops.finish()
+            assert ovf == 0
+            parts.append(res[:count].cpu().numpy().view(np.uint32).reshape(-1).view(
+                cuking_amd.KING_RESULT_DTYPE).copy())
+        merged = cuking_amd.sort_results(np.ascontiguousarray(np.concatenate(parts)))
+        assert merged.tobytes() == exp.tobytes()
         ctx.set_option("max_launch_blocks", 700)   # two launches, each with its own tail
         got = ctx.run(sm, bits.shape[1], d_bits, 0.07, max_results=1 << 20)
         assert got.tobytes() == exp.tobytes()
