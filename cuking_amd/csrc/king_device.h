@@ -58,36 +58,36 @@ __device__ __forceinline__ void emit_result(uint32_t i, uint32_t j, float kin,
 __device__ __forceinline__ uint32_t wave_hom_hom_count(
     const uint64_t *__restrict__ bits, uint32_t words_per_sample,
     uint32_t offset_i, uint32_t offset_j, uint32_t lane) {
+  typedef const __attribute__((address_space(1))) uint64_t *gptr;
   const uint32_t n = words_per_sample / 2;
-  const uint64_t *het_i = bits + (uint64_t)offset_i * words_per_sample;
-  const uint64_t *het_j = bits + (uint64_t)offset_j * words_per_sample;
+  // The two het planes: wave-uniform bases (SGPR pairs) + one lane offset, so
+  // that a trip's loads share their address registers.
+  auto uniform = [](const uint64_t *p) {
+    const uint64_t v = (uint64_t)p;
+    // (the builtin returns int: without the casts the low word is sign-extended)
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+    return (gptr)(((uint64_t)hi << 32) | lo);
+  };
+  const gptr het_i = uniform(bits + (uint64_t)offset_i * words_per_sample);
+  const gptr het_j = uniform(bits + (uint64_t)offset_j * words_per_sample);
   uint32_t c = 0;
   // The loop is one memory latency per trip (the planes of an arbitrary pair
   // are cold), so a trip requests 2 x 8 words per lane before it counts any:
   // a 100k-site pair takes 4 trips instead of 25 (tiles with ~40 related pairs
   // spent 350 us here, profiles/r02_tail.txt).
   constexpr uint32_t kAhead = 8;
-  uint32_t w = lane;
-  for (; w + 64 * (kAhead - 1) < n; w += 64 * kAhead) {
+  for (uint32_t w0 = 0; w0 < n; w0 += 64 * kAhead) {  // (uniform trip count)
     uint64_t x[kAhead], y[kAhead];
 #pragma unroll
     for (uint32_t k = 0; k < kAhead; ++k) {
-      x[k] = het_i[w + 64 * k];
-      y[k] = het_j[w + 64 * k];
+      const uint32_t w = w0 + 64 * k + lane;
+      const bool in = w < n;  // beyond the plane: counts as "het" = nothing
+      x[k] = in ? het_i[w] : ~0ull;
+      y[k] = in ? het_j[w] : ~0ull;
     }
 #pragma unroll
     for (uint32_t k = 0; k < kAhead; ++k) c += __popcll(~(x[k] | y[k]));
-  }
-  {
-    uint64_t x[kAhead - 1], y[kAhead - 1];
-#pragma unroll
-    for (uint32_t k = 0; k < kAhead - 1; ++k) {
-      const bool in = w + 64 * k < n;
-      x[k] = in ? het_i[w + 64 * k] : ~0ull;
-      y[k] = in ? het_j[w + 64 * k] : ~0ull;
-    }
-#pragma unroll
-    for (uint32_t k = 0; k < kAhead - 1; ++k) c += __popcll(~(x[k] | y[k]));
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);

@@ -226,6 +226,46 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   constexpr int BI = 2;              // 32-row blocks of the wavefront
   extern __shared__ uint4 lds[];  // [NSTAGE][side][k-group][plane][128]
 
+  // Which tile (SPLIT: which piece) this workgroup takes.
+  uint32_t bid = blockIdx.x;
+  uint32_t piece = 0;
+  if (a.dyn_tiles != 0 && blockIdx.x >= a.launch_tiles) {
+    // dynamic tail (king_common.h): the next tile (SPLIT: the next piece of the
+    // remainder) nobody has taken yet
+    // (every workgroup of the tail asks exactly once: the last one to ask leaves
+    // the counter ready for the next launch)
+    uint32_t *slot = reinterpret_cast<uint32_t *>(lds);
+    if (threadIdx.x == 0) {
+      uint32_t *counter = a.split_counters + dyn_counter_index(a.split_wgs);
+      const uint32_t asked = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+      if (asked == a.dyn_wgs - 1)
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *slot = asked;
+    }
+    __syncthreads();
+    const uint32_t t = __builtin_amdgcn_readfirstlane(*slot);
+    __syncthreads();  // the word is stage memory from here on
+    if (t >= a.dyn_tiles) return;  // uniform
+    if (SPLIT) piece = t; else bid = a.launch_tiles + t;
+  } else
+  // (SPLIT launches: the whole-tile workgroups in front take the patch order
+  // when their count is a multiple of 8 x 32; the pieces behind them do not)
+  if (a.xcd_chunk != 0 && (!SPLIT || blockIdx.x < a.split_whole)) {
+    const uint32_t x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    // xcd_chunk == 1: patches of 32 consecutive tiles dealt round-robin to the
+    // XCDs (XCD x takes patches x, x + 8, ...); otherwise one contiguous chunk
+    // of xcd_chunk tiles per XCD.
+#ifndef CUKING_XCD_XOR
+#define CUKING_XCD_XOR 0  // (experiment: which patches an XCD takes, profiles/r02_tail.txt)
+#endif
+    bid = a.xcd_chunk == 1 ? (((j >> 5) * 8 + (x ^ CUKING_XCD_XOR)) << 5) + (j & 31)
+                           : x * a.xcd_chunk + j;
+    if (bid >= a.launch_tiles) return;  // padding (uniform)
+  }
+  bid = __builtin_amdgcn_readfirstlane(bid);
+  piece = __builtin_amdgcn_readfirstlane(piece);
+
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t wr = (wave >> 1) * 64;  // wavefront's rows inside the tile
@@ -252,42 +292,6 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   [[maybe_unused]] uint32_t tl_seg = 0;  // (timeline build) segment of this workgroup
   const uint64_t units = (uint64_t)a.split_tiles * tile_steps;      // of the cut-up tiles
   const uint64_t whole_units = SPLIT ? (uint64_t)a.split_whole * tile_steps : 0;
-  uint32_t bid = blockIdx.x;
-  uint32_t piece = 0;
-  if (a.dyn_tiles != 0 && blockIdx.x >= a.launch_tiles) {
-    // dynamic tail (king_common.h): the next tile (SPLIT: the next piece of the
-    // remainder) nobody has taken yet
-    uint32_t *slot = reinterpret_cast<uint32_t *>(lds);
-    if (threadIdx.x == 0) {
-      uint32_t *counter = a.split_counters + dyn_counter_index(a.split_wgs);
-      const uint32_t t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED,
-                                                __HIP_MEMORY_SCOPE_AGENT);
-      // every workgroup of the tail asks exactly once: the last one to ask
-      // leaves the counter ready for the next launch
-      if (t == a.dyn_wgs - 1)
-        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *slot = t;
-    }
-    __syncthreads();
-    const uint32_t t = __builtin_amdgcn_readfirstlane(*slot);
-    __syncthreads();  // the word is stage memory from here on
-    if (t >= a.dyn_tiles) return;  // uniform
-    if (SPLIT) piece = t; else bid = a.launch_tiles + t;
-  } else
-  // (SPLIT launches: the whole-tile workgroups in front take the patch order
-  // when their count is a multiple of 8 x 32; the pieces behind them do not)
-  if (a.xcd_chunk != 0 && (!SPLIT || blockIdx.x < a.split_whole)) {
-    const uint32_t x = blockIdx.x & 7, j = blockIdx.x >> 3;
-    // xcd_chunk == 1: patches of 32 consecutive tiles dealt round-robin to the
-    // XCDs (XCD x takes patches x, x + 8, ...); otherwise one contiguous chunk
-    // of xcd_chunk tiles per XCD.
-#ifndef CUKING_XCD_XOR
-#define CUKING_XCD_XOR 0  // (experiment: which patches an XCD takes, profiles/r02_tail.txt)
-#endif
-    bid = a.xcd_chunk == 1 ? (((j >> 5) * 8 + (x ^ CUKING_XCD_XOR)) << 5) + (j & 31)
-                           : x * a.xcd_chunk + j;
-    if (bid >= a.launch_tiles) return;  // padding (uniform)
-  }
   const bool whole_wg = !SPLIT || blockIdx.x < a.split_whole;
 
   uint64_t unit_lo = whole_wg ? (uint64_t)bid * tile_steps
@@ -323,10 +327,11 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
                                                              : tile_steps - k_first);
   unit_lo += num_steps;
   if (SPLIT) {
-    unit_lo = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(unit_lo >> 32)) << 32) |
-              __builtin_amdgcn_readfirstlane((uint32_t)unit_lo);
-    unit_hi = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(unit_hi >> 32)) << 32) |
-              __builtin_amdgcn_readfirstlane((uint32_t)unit_hi);
+    // (the builtin returns int: the casts keep the low word from being sign-extended)
+    unit_lo = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(unit_lo >> 32)) << 32) |
+              (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)unit_lo);
+    unit_hi = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(unit_hi >> 32)) << 32) |
+              (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)unit_hi);
   }
   uint32_t tr, tc;
   if (!decode_tile(a, a.tile_begin + seg_tile, &tr, &tc)) continue;  // uniform
