@@ -70,13 +70,75 @@ def build_library(force: bool = False, save_temps: bool = False,
     # experiments: extra -D flags, e.g. CUKING_EXTRA_HIPFLAGS="-DCUKING_MFMA_STAGES=3"
     for flag in os.environ.get("CUKING_EXTRA_HIPFLAGS", "").split():
         cmd.insert(1, flag)
-    cwd = PKG
-    if save_temps:  # keeps the .s / resource-usage remarks for inspection
-        cwd = PKG / "build_tmp"
-        cwd.mkdir(exist_ok=True)
-        cmd += ["-save-temps", "-Rpass-analysis=kernel-resource-usage"]
-    subprocess.run(cmd, check=True, cwd=str(cwd))
+    # Always with -save-temps (in build_tmp/): the assembly of the matrix-core
+    # kernel is checked below.  --save-temps adds the resource-usage remarks on the
+    # console; otherwise the compiler's output goes to build_tmp/build.log.
+    cwd = PKG / "build_tmp"
+    cwd.mkdir(exist_ok=True)
+    cmd += ["-save-temps"]
+    if save_temps:
+        cmd += ["-Rpass-analysis=kernel-resource-usage"]
+        subprocess.run(cmd, check=True, cwd=str(cwd))
+    else:
+        with open(cwd / "build.log", "w") as log:
+            r = subprocess.run(cmd, cwd=str(cwd), stdout=log, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            sys.stderr.write((cwd / "build.log").read_text()[-8000:])
+            raise subprocess.CalledProcessError(r.returncode, cmd)
+    problems = check_mfma_loops(cwd / "king_mfma-hip-amdgcn-amd-amdhsa-gfx950.s")
+    if problems and not (tuning or os.environ.get("CUKING_EXTRA_HIPFLAGS")):
+        LIB_PATH.unlink(missing_ok=True)
+        raise RuntimeError("matrix-core kernel: the compiler put vector-memory waits or scratch "
+                           "accesses inside an LDS-DMA loop:\n  " + "\n  ".join(problems))
+    for line in problems:
+        print("warning (experiment build):", line, file=sys.stderr)
     return LIB_PATH
+
+
+def check_mfma_loops(asm_path: Path, verbose: bool = False):
+    """The LDS-DMA requests of king_mfma.hip are inline asm the compiler's wait-count
+    pass does not see, so ANY wait it inserts on the vector-memory counter inside
+    such a loop (for a spill reload or a load of its own still in flight at loop
+    entry) drains the whole prefetch pipeline every k-step -- 10 % of a launch the
+    one time it happened (round 2, full form).  Returns the offending loops: blocks
+    with LDS-DMA and >= 40 MFMAs that hold a scratch instruction or a vmcnt wait
+    other than the hand-counted vmcnt(16)."""
+    import re
+    text = Path(asm_path).read_text()
+    funcs = re.split(r"\n(?=_ZN6cuking12_GLOBAL__N_116king_mfma_kernel\w+:)", text)[1:]
+    if not funcs:
+        return [f"no king_mfma_kernel in {asm_path}"]
+    problems = []
+    for f in funcs:
+        m = re.match(r"_ZN6cuking12_GLOBAL__N_116king_mfma_kernelILb(\d)ELb(\d)ELi(\d)", f)
+        label = f"king_mfma_kernel<FULL={m.group(1)}, SPLIT={m.group(2)}, ABLATE={m.group(3)}>"
+        body = f.split(".Lfunc_end")[0]
+        seen = 0
+        for block in re.split(r"\n(?=\.LBB\d+_\d+:)", body):
+            lines = block.split("\n")
+            head = lines[0].split(":")[0]
+            # the loop proper ends at its back branch; what follows in the listing
+            # is the fall-through block
+            end = next((i for i, l in enumerate(lines)
+                        if re.search(r"s_cbranch_\w+ " + re.escape(head) + r"\b", l)), None)
+            if end is None:
+                continue
+            loop = lines[:end + 1]
+            mfma = sum("v_mfma" in l for l in loop)
+            if mfma < 40 or not any("global_load_lds" in l for l in loop):
+                continue  # (the full form's pass in front: compiler-counted loads, no LDS-DMA)
+            seen += 1
+            scratch = [l.strip() for l in loop if "scratch_" in l]
+            waits = [l.strip() for l in loop if re.search(r"s_waitcnt.*vmcnt\(\d+\)", l)]
+            foreign = [w for w in waits if "vmcnt(16)" not in w]
+            if verbose:
+                print(f"{label}: loop {head} ({mfma} MFMAs): scratch {len(scratch)}, "
+                      f"vmcnt waits {waits}")
+            if scratch or foreign:
+                problems.append(f"{label}, loop {head}: scratch {scratch[:2]}, waits {foreign}")
+        if seen == 0:
+            problems.append(f"{label}: no LDS-DMA loop found (listing format changed?)")
+    return problems
 
 
 def arrow_flags():

@@ -124,19 +124,40 @@ __device__ __attribute__((noinline)) void lean_epilogue_call(
   lean_epilogue_pair(c, valid, li, lj, het_i, het_j, both_het, opp, lane);
 }
 
-// The record append of the full form, out of line as well -- here for
-// correctness: inlined 64 times, the wave-level aggregation the compiler builds
-// around the atomic counter (whole-wave-mode temporaries) sat in the middle of
-// ~500 live registers, and the remainder-split instantiation then returned
-// wrong sums for whole tiles whenever only a few lanes emitted (staged
-// rectangles, threshold 0.0884: tools/fuzz_split.py seed 1 case 3; with every
-// lane emitting, or out of line, the same sums are right).  The decision whether
-// to call is wave-uniform.
-__device__ __attribute__((noinline)) void full_emit_call(
-    const EmitCtx c, uint32_t li, uint32_t lj, float kin, uint32_t ibs0, uint32_t ibs1,
-    uint32_t ibs2) {
-  emit_result(c.i_begin + li, c.j_begin + lj, kin, ibs0, ibs1, ibs2, c.max_results, c.results,
-              c.result_index, c.result_overflow);
+// Full form: a wavefront reserves the slots for ALL records of its 64 x 64 pairs
+// with one atomic (one lane), out of line.  History: the per-pair append
+// (atomicAdd in every lane, which the compiler turns into a wave-level
+// aggregation with whole-wave-mode temporaries) inlined 64 times among ~500 live
+// registers made the remainder-split instantiation return wrong sums for whole
+// tiles whenever only a few lanes emitted (tools/fuzz_split.py seed 1 case 3);
+// out of line per pair it was right but cost one atomic round trip per call --
+// 11 ms per 10^6 records at configs[1] when most pairs pass.
+// ... and the record itself (cuking.cu:297-313), out of line as well: the kernel
+// around it has no registers to spare for 64 inlined copies.
+__device__ __attribute__((noinline)) void full_store_call(
+    const EmitCtx c, uint32_t slot, uint32_t li, uint32_t lj, uint32_t het_i, uint32_t het_j,
+    uint32_t both_het, uint32_t opp, uint32_t hom_hom) {
+  if (slot >= c.max_results) {
+    atomicMax(c.result_overflow, 1u);
+    return;
+  }
+  const uint32_t ibs2 = hom_hom - opp + both_het;
+  const uint32_t shared = het_i + het_j - both_het + hom_hom;
+  cuking_result rec;
+  rec.sample_i = c.i_begin + li;
+  rec.sample_j = c.j_begin + lj;
+  rec.kin = king_kinship(het_i, het_j, both_het, opp);
+  rec.ibs0 = opp;
+  rec.ibs1 = shared - opp - ibs2;
+  rec.ibs2 = ibs2;
+  c.results[slot] = rec;
+}
+
+__device__ __attribute__((noinline)) uint32_t reserve_slots(uint32_t *result_index, uint32_t n) {
+  uint32_t base = 0;
+  if ((threadIdx.x & 63) == 0)
+    base = __hip_atomic_fetch_add(result_index, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (uint32_t)__builtin_amdgcn_readfirstlane(base);
 }
 
 // `n` MFMAs, each followed by `v` VALU instructions (scheduling request).
@@ -881,6 +902,69 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   // --- epilogue: kinship, threshold, append (cuking.cu:284-313).  C layout of
   // the 32 x 32 MFMA: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
   const EmitCtx emit_ctx = make_emit_ctx(a);
+  if (FULL && a.dense_counts == nullptr) {
+    // Full form, records: sweep 0 decides every pair (cuking.cu:284-297) and
+    // counts, ONE reservation for the wavefront's records, sweep 1 stores them
+    // (cuking.cu:297-313; slot order inside the reservation: sweep order, then
+    // lane).  The decisions of sweep 0 are kept, one bit per pair.
+    uint32_t total = 0, base = 0, run = 0;  // wave-uniform
+    uint32_t decided[BI * 2] = {};          // bit r of word (bi, bj)
+#pragma nounroll
+    for (int pass = 0; pass < 2; ++pass) {  // (one body: the kernel has no registers for two)
+#pragma unroll
+      for (int bi = 0; bi < BI; ++bi) {
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj) {
+          const uint32_t lj = tc * kTile + wc + bj * 32 + lr;
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const float4 h4 = park[((bi * 2 + bj) * 4 + r4) * 64];
+            const float hh[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+            for (int r1 = 0; r1 < 4; ++r1) {
+              const int r = 4 * r4 + r1;
+              const uint32_t li =
+                  tr * kTile + wr + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+              const uint32_t het_i = (uint32_t)acc[bi][bj][2][r];
+              const uint32_t het_j = (uint32_t)acc[bi][bj][3][r];
+              const uint32_t both_het = (uint32_t)acc[bi][bj][1][r];
+              const uint32_t opp = (uint32_t)acc[bi][bj][0][r];
+              if (pass == 0) {
+                // cuking.cu:199 plus the tile padding
+                const bool valid = li < a.geo.num_rows && lj < a.geo.num_cols &&
+                                   a.i_begin + li < a.j_begin + lj;
+                const bool emit =
+                    valid && king_kinship(het_i, het_j, both_het, opp) > a.kin_threshold;
+                decided[bi * 2 + bj] |= (emit ? 1u : 0u) << r;
+              } else {
+                const bool emit = (decided[bi * 2 + bj] >> r) & 1u;
+                const unsigned long long b = __ballot(emit);
+                if (b != 0) {  // wave-uniform
+                  const uint32_t before = __builtin_amdgcn_mbcnt_hi(
+                      (uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                  const uint32_t slot = base + run + before;
+                  run += (uint32_t)__popcll(b);
+                  if (emit)
+                    full_store_call(emit_ctx, slot, li, lj, het_i, het_j, both_het, opp,
+                                    (uint32_t)hh[r1]);
+                }
+              }
+            }
+          }
+        }
+      }
+      if (pass == 0) {
+        total = 0;
+#pragma unroll
+        for (int k = 0; k < BI * 2; ++k) total += (uint32_t)__popc(decided[k]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+        total = (uint32_t)__builtin_amdgcn_readfirstlane(total);
+        if (total == 0) break;  // wave-uniform
+        base = reserve_slots(a.result_index, total);
+      }
+    }
+  } else {
 #pragma unroll
   for (int bi = 0; bi < BI; ++bi) {
 #pragma unroll
@@ -903,22 +987,10 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
         const bool valid = li < a.geo.num_rows && lj < a.geo.num_cols &&
                            a.i_begin + li < a.j_begin + lj;
         if (FULL) {
-          // cuking.cu:284-313 with all five sums at hand
-          const uint32_t het_i = (uint32_t)acc[bi][bj][2][r], het_j = (uint32_t)acc[bi][bj][3][r];
-          const uint32_t both_het = (uint32_t)acc[bi][bj][1][r], opp = (uint32_t)acc[bi][bj][0][r];
-          const uint32_t hom_hom = (uint32_t)hh[r];
-          if (a.dense_counts != nullptr) {
-            full_epilogue_pair(a, valid, li, lj, het_i, het_j, both_het, opp, hom_hom);
-          } else {
-            const float kin = king_kinship(het_i, het_j, both_het, opp);
-            const bool emit = valid && kin > a.kin_threshold;
-            if (__ballot(emit) != 0) {      // wave-uniform
-              const uint32_t conc = hom_hom - opp;
-              const uint32_t shared = het_i + het_j - both_het + hom_hom;
-              const uint32_t ibs2 = conc + both_het;
-              if (emit) full_emit_call(emit_ctx, li, lj, kin, opp, shared - opp - ibs2, ibs2);
-            }
-          }
+          // diagnostic counts: cuking.cu:284-313 with all five sums at hand
+          full_epilogue_pair(a, valid, li, lj, (uint32_t)acc[bi][bj][2][r],
+                             (uint32_t)acc[bi][bj][3][r], (uint32_t)acc[bi][bj][1][r],
+                             (uint32_t)acc[bi][bj][0][r], (uint32_t)hh[r]);
         } else {
           // Nearly every pair fails the threshold: decide that on the float
           // sums without the IEEE divide, and only when some lane of the
@@ -935,6 +1007,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
         }
       }
     }
+  }
   }
   if (SPLIT) __syncthreads();  // LDS is reused by the next piece
   CUKING_TL(5 + 5 * tl_seg)
