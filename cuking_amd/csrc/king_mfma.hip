@@ -363,37 +363,62 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   const uint4 *g_rows = a.planes + (uint64_t)tr * kTile;
   const uint4 *g_cols = a.planes + a.geo.col_base + (uint64_t)tc * kTile;
 
-  // Requests row r (1 KiB) of this wavefront's share of k-step
-  // min(step, last) into LDS buffer `buf`.  Clamping keeps the number of DMAs
-  // in flight the same in every iteration, so one counted wait serves the
-  // whole loop; the repeats of the last step land in a buffer nobody reads.
-  auto issue_piece = [&](uint32_t step, uint32_t buf, int r) {
-    if (ABLATE == 1 || ABLATE == 2) return;
-    const uint32_t row = wave * kPiecesPerWave + r;  // 1 KiB row of the stage, 0..15
-    const uint32_t side = row >> 3, kg = (row >> 2) & 1;
-    const uint32_t p = (row >> 1) & 1, seg = row & 1;
+  // LDS-DMA addressing.  Row `row` = 4 wave + r (1 KiB) of a stage is
+  // (side, k-group, plane p, half seg) = (row >> 3, row >> 2 & 1, row >> 1 & 1,
+  // row & 1): a wavefront's four requests share side and k-group, and r = 2 p +
+  // seg, so that seg moves source and destination by the same 1 KiB -- the
+  // instruction's immediate offset, which is added to both -- and only p needs
+  // addresses of its own.  Per k-step that is one multiply for the wave-uniform
+  // source row and a handful of scalar adds; `piece_addr` is called a phase ahead
+  // of the requests, so that this arithmetic does not sit in the MFMA gaps that
+  // already hold a request (it was 6-18 scalar instructions per request there).
+  const uint32_t dma_side = wave >> 1, dma_kg = wave & 1;
+  const uint4 *const g_wave = (dma_side ? g_cols : g_rows) +
+                              ((uint64_t)(2 * k_first + dma_kg) * 2) * s_stride;
+  const uint32_t l_wave = (uint32_t)(uintptr_t)(lds_void_ptr)(
+      lds + ((dma_side * 2 + dma_kg) * 2) * kTile);
+  struct PieceAddr { const uint4 *src[2]; uint32_t dst[2]; };
+  // Source rows / LDS addresses of k-step min(step, last) -> buffer `buf`.
+  // Clamping keeps the number of DMAs in flight the same in every iteration,
+  // so one counted wait serves the whole loop; the repeats of the last step
+  // land in a buffer nobody reads.
+  auto piece_addr = [&](uint32_t step, uint32_t buf) {
+    PieceAddr pa;
     if (step >= num_steps) step = num_steps - 1;
-    step += k_first;
-    // Wave-uniform source row (SGPR pair) + one per-lane byte offset: no
-    // per-request address arithmetic in vector registers.
-    const uint4 *src = (side ? g_cols : g_rows) +
-                       ((uint64_t)(2 * step + kg) * 2 + p) * s_stride + seg * 64;
-    uint4 *dst = lds + buf * kStageU4 + ((side * 2 + kg) * 2 + p) * kTile +
-                 seg * 64;
-    // LDS-DMA, lane l's 16 bytes land at dst + 16 * l.  Inline asm keeps it
-    // out of the compiler's wait-count bookkeeping (king_kernels.hip).
-    const uint32_t lds_addr = (uint32_t)(uintptr_t)(lds_void_ptr)dst;
-    asm volatile(
-        "s_mov_b32 m0, %0\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2"
-        :
-        : "s"(lds_addr), "v"(lane16), "s"(src)
-        : "memory", "m0");
+    pa.src[0] = g_wave + (uint64_t)step * 4 * s_stride;
+    pa.src[1] = pa.src[0] + s_stride;
+    pa.dst[0] = l_wave + buf * (kStageU4 * 16);
+    pa.dst[1] = pa.dst[0] + kTile * 16;
+    // materialised here, not where the requests are
+    asm volatile("" : "+s"(pa.src[0]), "+s"(pa.src[1]), "+s"(pa.dst[0]), "+s"(pa.dst[1]));
+    return pa;
+  };
+  // Request r of the four.  LDS-DMA, lane l's 16 bytes land at dst + 16 * l.
+  // Inline asm keeps it out of the compiler's wait-count bookkeeping
+  // (king_kernels.hip).
+  auto issue_piece = [&](const PieceAddr &pa, int r) {
+    if (ABLATE == 1 || ABLATE == 2) return;
+    if (r & 1)
+      asm volatile(
+          "s_mov_b32 m0, %0\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, %2 offset:1024"
+          :
+          : "s"(pa.dst[r >> 1]), "v"(lane16), "s"(pa.src[r >> 1])
+          : "memory", "m0");
+    else
+      asm volatile(
+          "s_mov_b32 m0, %0\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, %2"
+          :
+          : "s"(pa.dst[r >> 1]), "v"(lane16), "s"(pa.src[r >> 1])
+          : "memory", "m0");
   };
   auto issue_stage = [&](uint32_t step, uint32_t buf) {
+    const PieceAddr pa = piece_addr(step, buf);
 #pragma unroll
-    for (int r = 0; r < kPiecesPerWave; ++r) issue_piece(step, buf, r);
+    for (int r = 0; r < kPiecesPerWave; ++r) issue_piece(pa, r);
   };
   // All but the kStages - 2 youngest stages requested so far have landed, for
   // this wavefront (counted wait) and, after the barrier, for all of them;
@@ -678,13 +703,15 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       CUKING_PACE(4, 0) CUKING_PACE(16, 4)                                     \
       __builtin_amdgcn_sched_barrier(0);
 #endif
-    // One k-step: requests stage STEP + AHEAD into the buffer BACK behind the
-    // current one; SYNC = hand stages over (wait + barrier) before the next
-    // k-step's LDS reads.
-#define CUKING_KSTEP(STEP, SYNC, AHEAD, BACK)                                  \
+    // One k-step.  Its four requests go to the addresses the k-step before it
+    // worked out (`pa`); in phase f = 3, where the MFMA gaps have room for scalar
+    // instructions, it works out those of the NEXT k-step, which requests stage
+    // STEP + 1 + NAHEAD into the buffer NBACK behind its own.  SYNC = hand stages
+    // over (wait + barrier) before the next k-step's LDS reads.
+#define CUKING_KSTEP(STEP, SYNC, NAHEAD, NBACK)                                \
     {                                                                          \
       const uint32_t nbuf = buf == NSTAGE - 1 ? 0 : buf + 1;                   \
-      const uint32_t dbuf = buf >= (BACK) ? buf - (BACK) : buf + NSTAGE - (BACK); \
+      const PieceAddr pa_ = pa;                                                \
       /* f = 0 multiplies, f = 1 is built */                                   \
       CUKING_EXPAND(Y, A, B, m2)                                               \
       CUKING_MMA16(0, X)                                                       \
@@ -692,7 +719,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       __builtin_amdgcn_sched_barrier(0);                                       \
       CUKING_STAMP(0)                                                          \
       _Pragma("unroll") for (int r = 0; r < 4; ++r) {                          \
-        issue_piece((STEP) + (AHEAD), dbuf, r);                                \
+        issue_piece(pa_, r);                                                   \
         acc[r >> 1][r & 1][0] =                                                \
             mma<0>(Xa[r >> 1][1], Xb[r & 1][0], acc[r >> 1][r & 1][0]);        \
         __builtin_amdgcn_sched_barrier(0);                                     \
@@ -712,18 +739,24 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       CUKING_STAMP(2)                                                          \
       CUKING_PHASE_F2(SYNC)                                                    \
       CUKING_STAMP(3)                                                          \
+      pa = piece_addr((STEP) + 1 + (NAHEAD),                                   \
+                      nbuf >= (NBACK) ? nbuf - (NBACK) : nbuf + NSTAGE - (NBACK)); \
       CUKING_PHASE_F3(SYNC)                                                    \
       CUKING_STAMP(5)                                                          \
       buf = nbuf;                                                              \
     }
     CUKING_TL(2 + 5 * tl_seg)
+    // (the first k-step requests stage NSTAGE - 1 into the buffer behind its own)
+    PieceAddr pa = piece_addr(NSTAGE - 1, buf >= 1 ? buf - 1 : buf + NSTAGE - 1);
     if constexpr (PAIRED) {
+      // even k-steps request stage + NSTAGE - 1 one buffer back, odd ones
+      // stage + NSTAGE - 3 three buffers back
       uint32_t step = 0;
       for (; step + 2 < num_steps; step += 2) {
-        CUKING_KSTEP(step, false, NSTAGE - 1, 1)
-        CUKING_KSTEP(step + 1, true, NSTAGE - 3, 3)
+        CUKING_KSTEP(step, false, NSTAGE - 3, 3)
+        CUKING_KSTEP(step + 1, true, NSTAGE - 1, 1)
       }
-      if (step + 1 < num_steps) CUKING_KSTEP(step, false, NSTAGE - 1, 1)
+      if (step + 1 < num_steps) CUKING_KSTEP(step, false, NSTAGE - 3, 3)
     } else {
       for (uint32_t step = 0; step + 1 < num_steps; ++step)
         CUKING_KSTEP(step, true, NSTAGE - 1, 1)
