@@ -1272,25 +1272,37 @@ cuking_status cuking_timing_collect(cuking_ctx *ctx, double *king_ms,
   mfma_timeline_dump();  // diagnostic build: the last matrix-core launch
 #endif
 #ifdef CUKING_MFMA_STAMPS
-  // diagnostic build: per-phase cycles of the matrix-core kernel's k-step
+  // diagnostic build: per-phase cycles of the matrix-core kernel's k-step, for
+  // k-steps without (row 0) and with (row 1) a stage hand-over
   for (auto &e : ctx->split_scratch) {
-    std::vector<unsigned long long> h(1024 * 8);
+    std::vector<unsigned long long> h(1024 * 16);
     uint32_t *scratch = e.second + mfma_split_counter_bytes(ctx->split_wgs) / sizeof(uint32_t);
     if (hipMemcpy(h.data(), scratch, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) break;
-    double sum[6] = {0, 0, 0, 0, 0, 0}, steps = 0;
+    double sum[2][6] = {}, steps = 0;
     int n = 0;
     for (int b = 0; b < 1024; ++b)
-      if (h[b * 8 + 7] == 0x5354414D50ull) {
-        for (int k = 0; k < 6; ++k) sum[k] += (double)h[b * 8 + k];
-        steps += (double)h[b * 8 + 6];
+      if (h[b * 16 + 7] == 0x5354414D50ull) {
+        for (int k = 0; k < 6; ++k) sum[0][k] += (double)h[b * 16 + k];
+        for (int k = 0; k < 6; ++k) sum[1][k] += (double)h[b * 16 + 8 + k];
+        steps += (double)h[b * 16 + 6];
         ++n;
       }
-    if (n)
-      fprintf(stderr,
-              "mfma stamps (%d workgroups): cycles per k-step  f0 %.0f | dma %.0f | f1 %.0f | f2 %.0f "
-              "| sync %.0f | f3 %.0f | total %.0f\n",
-              n, sum[0] / steps, sum[1] / steps, sum[2] / steps, sum[3] / steps, sum[4] / steps,
-              sum[5] / steps, (sum[0] + sum[1] + sum[2] + sum[3] + sum[4] + sum[5]) / steps);
+    if (n) {
+      bool both = false;
+      for (int k = 0; k < 6; ++k) both = both || (sum[0][k] != 0 && sum[1][k] != 0);
+      const double per_row = both ? steps / 2 : steps;
+      for (int r = 0; r < 2; ++r) {
+        double t = 0;
+        for (int k = 0; k < 6; ++k) t += sum[r][k];
+        if (t == 0) continue;
+        fprintf(stderr,
+                "mfma stamps (%d workgroups, k-steps %s hand-over): cycles per k-step  f0 %.0f | "
+                "dma %.0f | f1 %.0f | f2 %.0f | sync %.0f | f3 %.0f | total %.0f\n",
+                n, r ? "with" : "without", sum[r][0] / per_row, sum[r][1] / per_row,
+                sum[r][2] / per_row, sum[r][3] / per_row, sum[r][4] / per_row, sum[r][5] / per_row,
+                t / per_row);
+      }
+    }
   }
 #endif
   if (king_ms) *king_ms = a;

@@ -67,17 +67,23 @@ constexpr int kPiecesPerWave = 4;            // 16 x 1 KiB per stage, 4 wavefron
 // is multiplied, i.e. kStages - 2 k-steps (~1.4 us each) of HBM latency are
 // covered.
 constexpr int kStages = CUKING_MFMA_STAGES;
-// Lean form (no LDS needed for a parked sum): two more stages, which is what it
+// Lean form (no LDS needed for a parked sum): more stages, at least the two it
 // takes to hand stages over with one barrier per TWO k-steps.
 #ifndef CUKING_MFMA_PAIRED
 #define CUKING_MFMA_PAIRED 1
 #endif
 constexpr bool kPairedSync = CUKING_MFMA_PAIRED != 0 && kStages == 6;
-constexpr int kStagesPaired = 8;
-// s_waitcnt vmcnt(N) immediate, N = DMAs of the kStages - 2 younger stages.
-constexpr int kYoungerDmas = 4 * kPiecesPerWave;  // both hand-over schemes, see the kernel
-static_assert(kYoungerDmas < 64, "vmcnt is a 6-bit counter");
-constexpr int kWaitStage = 0x0F70 | (kYoungerDmas & 15) | ((kYoungerDmas >> 4) << 14);
+#ifndef CUKING_MFMA_PAIRED_STAGES
+// even, 8 or 10.  10 x 16 KiB is the CU's whole LDS and puts 5.5 instead of 3.5
+// k-steps between a request and the hand-over that needs it: configs[2] 593 ->
+// 590 ms, 40k x 100k 95.2 -> 94.7 ms, configs[1] (bitset in the Infinity Cache) equal
+// (tools/exp25.sh).
+#define CUKING_MFMA_PAIRED_STAGES 10
+#endif
+constexpr int kStagesPaired = CUKING_MFMA_PAIRED_STAGES;
+static_assert(kStagesPaired % 2 == 0 && kStagesPaired >= 8 && kStagesPaired <= 10, "stages");
+// s_waitcnt vmcnt(N) immediate for N requests that may stay in flight.
+constexpr int vmcnt_imm(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
 
 // v_bitop3_b32 truth tables over (het, hom_var, mask), index = 4 het + 2 hom + mask.
 constexpr int kA = 0x08;  // hom-alt:  ~het &  hom & mask
@@ -197,11 +203,13 @@ void timeline_arm(uint32_t whole, uint32_t blocks);
   {                                                                            \
     unsigned long long now_;                                                   \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
-    stamp_sum[K] += now_ - stamp_last;                                         \
+    stamp_sum[(K) + stamp_row] += now_ - stamp_last;                           \
     stamp_last = now_;                                                         \
   }
+#define CUKING_STAMP_ROW(SYNC) stamp_row = (SYNC) ? 6 : 0;
 #else
 #define CUKING_STAMP(K)
+#define CUKING_STAMP_ROW(SYNC)
 #endif
 
 // Tickets: one per workgroup and pass (the full form makes two).
@@ -426,7 +434,10 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   // overwrites.
   auto stage_sync = [&]() {
     if (ABLATE == 2) return;
-    __builtin_amdgcn_s_waitcnt(kWaitStage);  // vmcnt(kYoungerDmas)
+    // unpaired: the NSTAGE - 2 younger stages; paired: NSTAGE - 4 (see below)
+    constexpr int younger = (PAIRED ? NSTAGE - 4 : NSTAGE - 2) * kPiecesPerWave;
+    static_assert(younger < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(younger));
     __syncthreads();
   };
 
@@ -596,7 +607,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
 
   // Stage hand-over.  Unpaired (full form): stage s + NSTAGE - 1 is requested
   // while stage s is multiplied, into the buffer stage s - 1 left, and every
-  // k-step ends with the counted wait + barrier.  Paired (lean form, 8 stages):
+  // k-step ends with the counted wait + barrier.  Paired (lean form; written for 8 stages):
   // the barrier comes only at the end of ODD k-steps and then covers the next
   // TWO stages.  A request may only overwrite a buffer whose last readers are
   // separated from it by a barrier; the reads of stage k happen at the end of
@@ -607,7 +618,9 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   // then 0..5, 7, 6, 9, 8, ...: when B(s) (s odd) waits for all but the 16
   // youngest requests of the wavefront, those are stages s+4, s+3, s+6, s+5,
   // i.e. stages s+1 and s+2 -- read at the end of k-steps s and s+1 -- have
-  // landed: the same vmcnt(16) as the unpaired form.
+  // landed: the same vmcnt(16) as the unpaired form.  (In general, N stages:
+  // even k-steps request stage i + N - 1, odd ones i + N - 3, and the wait
+  // leaves the N - 4 youngest stages in flight.)
   constexpr int kPrologueStages = PAIRED ? NSTAGE - 2 : NSTAGE - 1;
 #pragma unroll
   for (int st = 0; st < kPrologueStages; ++st) issue_stage(st, st);
@@ -632,7 +645,9 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     // s_waitcnt vmcnt(0) there, draining the DMA pipeline in every iteration.
     asm volatile("" : "+v"(row_off), "+v"(col_off), "+v"(lane16));
 #ifdef CUKING_MFMA_STAMPS
-    unsigned long long stamp_sum[6] = {0, 0, 0, 0, 0, 0}, stamp_last;
+    // rows: k-steps without / with a stage hand-over
+    unsigned long long stamp_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+    [[maybe_unused]] int stamp_row = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
 #endif
     // Where a k-step's LDS reads of the NEXT k-step go (tools/exp14.sh, one box,
@@ -712,6 +727,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     {                                                                          \
       const uint32_t nbuf = buf == NSTAGE - 1 ? 0 : buf + 1;                   \
       const PieceAddr pa_ = pa;                                                \
+      CUKING_STAMP_ROW(SYNC)                                                   \
       /* f = 0 multiplies, f = 1 is built */                                   \
       CUKING_EXPAND(Y, A, B, m2)                                               \
       CUKING_MMA16(0, X)                                                       \
@@ -767,8 +783,9 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
 #ifdef CUKING_MFMA_STAMPS
     if (!SPLIT && a.split_scratch != nullptr && blockIdx.x < 1024 && threadIdx.x == 0) {
       unsigned long long *dbg =
-          reinterpret_cast<unsigned long long *>(a.split_scratch) + (size_t)blockIdx.x * 8;
+          reinterpret_cast<unsigned long long *>(a.split_scratch) + (size_t)blockIdx.x * 16;
       for (int k = 0; k < 6; ++k) dbg[k] = stamp_sum[k];
+      for (int k = 0; k < 6; ++k) dbg[8 + k] = stamp_sum[6 + k];
       dbg[6] = num_steps - 1;
       dbg[7] = 0x5354414D50ull;  // "STAMP"
     }
