@@ -259,3 +259,26 @@ def test_narrow_triples_matches_pack_host(oracle):
     assert lib.cuking_narrow_triples(C.byref(sm.c), wps, r_.ctypes.data, c_.ctypes.data,
                                      a_.ctypes.data, 1, buf.ctypes.data, buf[2:].ctypes.data,
                                      C.byref(kept)) == 0 and kept.value == 0
+
+
+def test_matrix_core_loops_hold_no_foreign_waits():
+    """The LDS-DMA requests of king_mfma.hip are inline asm the compiler's wait-count
+    pass cannot see: a spill reload (or any load of its own) still in flight at the
+    top of a k-loop makes it insert `s_waitcnt vmcnt(0)` there, which drains the whole
+    prefetch pipeline every k-step (-10 % once).  Every library build checks the
+    assembly it leaves in build_tmp/; so does this test, on the library under test."""
+    from cuking_amd import build
+    asm = build.PKG / "build_tmp" / "king_mfma-hip-amdgcn-amd-amdhsa-gfx950.s"
+    if not asm.exists() or asm.stat().st_mtime < (build.CSRC / "king_mfma.hip").stat().st_mtime:
+        build.build_library(force=True)
+    assert build.check_mfma_loops(asm) == []
+    # and the checker itself notices what it is there for
+    text = asm.read_text()
+    bad = text.replace("s_waitcnt vmcnt(24)", "s_waitcnt vmcnt(0)\n\ts_waitcnt vmcnt(24)", 1)
+    assert bad != text
+    broken = asm.with_suffix(".broken.s")
+    broken.write_text(bad)
+    try:
+        assert build.check_mfma_loops(broken) != []
+    finally:
+        broken.unlink()
