@@ -274,7 +274,7 @@ def test_matrix_core_loops_hold_no_foreign_waits():
     assert build.check_mfma_loops(asm) == []
     # and the checker itself notices what it is there for
     text = asm.read_text()
-    bad = text.replace("s_waitcnt vmcnt(24)", "s_waitcnt vmcnt(0)\n\ts_waitcnt vmcnt(24)", 1)
+    bad = text.replace("s_waitcnt vmcnt(24)", "s_waitcnt vmcnt(0)\n\ts_waitcnt vmcnt(24)")
     assert bad != text
     broken = asm.with_suffix(".broken.s")
     broken.write_text(bad)
