@@ -315,7 +315,10 @@ std::string RunMultiGpu(const MultiGpuInput &in, MultiGpuOutput *out, std::strin
   std::vector<int> devices(in.num_gpus);
   for (int r = 0; r < in.num_gpus; ++r) devices[r] = in.first_device + r;
   sh.comms.assign(in.num_gpus, nullptr);
+  const auto init_t0 = std::chrono::steady_clock::now();
   const ncclResult_t rc = ncclCommInitAll(sh.comms.data(), in.num_gpus, devices.data());
+  out->comm_init_seconds =
+      std::chrono::duration<double>(std::chrono::steady_clock::now() - init_t0).count();
   if (rc != ncclSuccess)
     return fail("INTERNAL", std::string("ncclCommInitAll failed: ") + ncclGetErrorString(rc));
 

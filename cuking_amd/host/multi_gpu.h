@@ -37,6 +37,7 @@ struct MultiGpuOutput {
   std::vector<cuking_result> results;  // all ranks', unsorted
   std::string mode;                    // the schedule that ran
   double exchange_and_compute_seconds = 0, gather_seconds = 0;
+  double comm_init_seconds = 0;        // ncclCommInitAll (seconds on a cold process)
   std::vector<double> rank_kernel_ms, rank_prepare_ms;
   std::vector<uint32_t> rank_results;
   uint64_t bytes_broadcast = 0;
