@@ -95,6 +95,8 @@ SIGNATURES = {
     "cuking_compute_king_rect": (_int, [_vp, _SM, _u32, _vp, _u32, _u32, _u32,
                                         _u32, _u32, _f32, _u32, _vp, _vp, _vp,
                                         _vp]),
+    "cuking_ctx_reserve": (_int, [_vp, _SM, _u32, C.POINTER(_vp), _sz]),
+    "cuking_invalidate": (_int, [_vp]),
     "cuking_compute_counts": (_int, [_vp, _SM, _u32, _vp, _vp, _vp]),
     "cuking_sort_results": (None, [_vp, _sz]),
     "cuking_timing_enable": (_int, [_vp, _int]),
@@ -140,7 +142,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so lacks a symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.cuking_abi_version() != 1:
+    if lib.cuking_abi_version() != 2:
         raise ImportError("libcuking_amd.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

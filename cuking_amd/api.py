@@ -242,6 +242,20 @@ class KingContext:
             result_index.data_ptr(), result_overflow.data_ptr(),
             _stream_handle(stream)))
 
+    def reserve(self, submatrix: Submatrix, words_per_sample: int, streams=()) -> None:
+        """Sizes the workspace for the block (and the split slabs of the
+        streams named) up front: later compute / prepare calls on those streams
+        neither allocate nor wait for the device."""
+        handles = (C.c_void_p * max(len(streams), 1))(
+            *[_stream_handle(s) for s in streams])
+        check(self.lib.cuking_ctx_reserve(
+            self.handle, C.byref(submatrix.c), words_per_sample, handles, len(streams)))
+
+    def invalidate(self) -> None:
+        """The bitset behind the pointer last converted has been rewritten in
+        place (only matters with the option "reuse_prepared")."""
+        check(self.lib.cuking_invalidate(self.handle))
+
     def compute_counts(self, submatrix: Submatrix, words_per_sample: int,
                        bit_sets, stream=None) -> np.ndarray:
         """Diagnostic: the six sums (cuking.cu:232-239) of every pair, as a

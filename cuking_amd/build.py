@@ -23,6 +23,8 @@ LIB_PATH = PKG / "libcuking_amd.so"
 CLI_PATH = PKG / "bin" / "cuking"
 
 HIP_SOURCES = ["king_abi.hip", "king_kernels.hip", "king_mfma.hip", "synth.hip"]
+# Host-only half of the ABI: plain C++, also compiled by the sanitizer tests.
+HOST_ABI_SOURCES = ["king_host.cc"]
 # IEEE-correct fp32 divide (kinship must match the reference bit for bit):
 # no fast-math, no contraction, correctly rounded divide/sqrt stays on.
 HIP_FLAGS = [
@@ -57,9 +59,9 @@ def build_library(force: bool = False, save_temps: bool = False,
                   tuning: bool = False) -> Path:
     """tuning=True adds timing-only experiment kernels (-DCUKING_TUNING); never
     the shipped configuration (build() and the tests use the default)."""
-    srcs = [CSRC / s for s in HIP_SOURCES]
-    deps = srcs + [CSRC / "king_common.h", CSRC / "king_device.h",
-                   INCLUDE / "cuking_amd.h",
+    srcs = [CSRC / s for s in HIP_SOURCES + HOST_ABI_SOURCES]
+    deps = srcs + [CSRC / "king_common.h", CSRC / "king_device.h", CSRC / "king_host.h",
+                   CSRC / "king_submatrix.h", INCLUDE / "cuking_amd.h",
                    Path(__file__)]
     if not force and _newer(LIB_PATH, deps):
         return LIB_PATH

@@ -15,29 +15,18 @@
 #include <vector>
 
 #include "king_common.h"
+#include "king_host.h"
 
 using namespace cuking;
 
 namespace {
-
-thread_local std::string g_last_error;
-
-cuking_status fail(cuking_status code, const char *fmt, ...) {
-  char buf[512];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof(buf), fmt, ap);
-  va_end(ap);
-  g_last_error = buf;
-  return code;
-}
 
 #define HIP_TRY(expr)                                                      \
   do {                                                                     \
     const hipError_t _e = (expr);                                          \
     if (_e != hipSuccess) {                                                \
       (void)hipGetLastError(); /* do not leave it sticky for other users */ \
-      return fail(_e == hipErrorOutOfMemory ? CUKING_ERR_OUT_OF_MEMORY     \
+      return cuking_fail(_e == hipErrorOutOfMemory ? CUKING_ERR_OUT_OF_MEMORY     \
                                             : CUKING_ERR_DEVICE,           \
                   "%s failed: %s", #expr, hipGetErrorString(_e));          \
     }                                                                      \
@@ -141,6 +130,16 @@ struct cuking_ctx {
   // with an event to order a later rewrite after them.
   std::vector<std::pair<hipStream_t, hipEvent_t>> readers;
 
+  // Hosts that promise not to rewrite a bitset in place without telling
+  // (cuking_invalidate) may skip the conversion when the workspace already
+  // holds this block ("reuse_prepared"); off by default: like the reference's
+  // kernel, a call then reads whatever the bitset holds when it runs.
+  bool reuse_prepared = false;
+  // Book-keeping for hosts that must not allocate or synchronise while
+  // collectives of other devices are in flight (cuking_ctx_reserve): device
+  // allocations made for the workspace, and host-side waits, so far.
+  uint64_t workspace_allocations = 0, host_syncs = 0, conversions_skipped = 0;
+
   bool timing = false;
   Timer king_timer, prepare_timer;
 };
@@ -188,7 +187,7 @@ bool use_full_counts(const cuking_ctx *ctx, float kin_threshold, bool dense,
 }
 
 cuking_status bind(cuking_ctx *ctx) {
-  if (ctx == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null context");
+  if (ctx == nullptr) return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null context");
   HIP_TRY(hipSetDevice(ctx->device));
   return CUKING_OK;
 }
@@ -253,11 +252,13 @@ cuking_status split_scratch_for(cuking_ctx *ctx, hipStream_t stream,
     if (ctx->split_scratch.size() >= 8) {
       // Streams come and go (torch hands out new handles): keep the cache
       // small.  Nothing may still be using a slab we free.
+      ++ctx->host_syncs;
       HIP_TRY(hipDeviceSynchronize());
       for (auto &e : ctx->split_scratch) (void)hipFree(e.second);
       ctx->split_scratch.clear();
     }
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base), bytes));
+    ++ctx->workspace_allocations;
     // The tickets must read zero when the first launch on this stream starts:
     // zero them ON that stream (a null-stream memset is not ordered against a
     // non-blocking stream, and fresh memory holds whatever was there before).
@@ -270,25 +271,6 @@ cuking_status split_scratch_for(cuking_ctx *ctx, hipStream_t stream,
   }
   *counters = base;
   *scratch = base + mfma_split_counter_bytes(ctx->split_wgs) / sizeof(uint32_t);
-  return CUKING_OK;
-}
-
-cuking_status check_block(const cuking_submatrix *sm,
-                          uint32_t words_per_sample) {
-  if (sm == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null submatrix");
-  if (sm->i_end < sm->i_begin || sm->j_end < sm->j_begin)
-    return fail(CUKING_ERR_INVALID_ARGUMENT, "submatrix ranges are reversed");
-  if (!sm_is_diag(*sm) && sm->j_begin < sm->i_end && sm_num_rows(*sm) != 0 &&
-      sm_num_cols(*sm) != 0)
-    return fail(CUKING_ERR_INVALID_ARGUMENT,
-                "row and column ranges must be identical or disjoint with "
-                "rows first");
-  if (sm_is_diag(*sm) && sm->i_end != sm->j_end)
-    return fail(CUKING_ERR_INVALID_ARGUMENT,
-                "a diagonal block needs identical row and column ranges");
-  if (words_per_sample == 0 || (words_per_sample & 1))
-    return fail(CUKING_ERR_INVALID_ARGUMENT,
-                "words_per_sample must be a positive even number");
   return CUKING_OK;
 }
 
@@ -322,6 +304,7 @@ cuking_status wait_for_readers(cuking_ctx *ctx, hipStream_t stream) {
   }
   if (failed) {
     (void)hipGetLastError();
+    ++ctx->host_syncs;
     HIP_TRY(hipDeviceSynchronize());
   }
   for (auto &r : ctx->readers)
@@ -351,6 +334,55 @@ bool same_block(const cuking_ctx::Prepared &p, const cuking_submatrix &sm,
          p.bits == bits;
 }
 
+// Makes the plane workspace at least `need` bytes and the band prefix at least
+// `entries` long.  Replacing either waits for the whole device first: kernels
+// of earlier calls (possibly on other streams) may still read the old one.
+cuking_status ensure_workspace(cuking_ctx *ctx, size_t need, size_t entries) {
+  if (need > ctx->planes_bytes) {
+    ++ctx->host_syncs;
+    HIP_TRY(hipDeviceSynchronize());
+    if (ctx->planes) HIP_TRY(hipFree(ctx->planes));
+    ctx->planes = nullptr;
+    ctx->planes_bytes = 0;
+    ctx->prepared.valid = false;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->planes), need));
+    ++ctx->workspace_allocations;
+    ctx->planes_bytes = need;
+  }
+  if (entries > ctx->band_prefix_entries) {
+    ++ctx->host_syncs;
+    HIP_TRY(hipDeviceSynchronize());
+    if (ctx->band_prefix) HIP_TRY(hipFree(ctx->band_prefix));
+    ctx->band_prefix = nullptr;
+    ctx->band_prefix_entries = 0;
+    ctx->prefix_for = TileSpace{0, 0, 0, 0};
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->band_prefix), entries * sizeof(uint64_t)));
+    ++ctx->workspace_allocations;
+    ctx->band_prefix_entries = entries;
+  }
+  return CUKING_OK;
+}
+
+bool same_tile_space(const TileSpace &a, const TileSpace &b) {
+  return a.tiles_r == b.tiles_r && a.tiles_c == b.tiles_c && a.band_rows == b.band_rows &&
+         a.diag == b.diag;
+}
+
+// Uploads the band prefix of `tiles` (the caller has ordered `stream` behind
+// the readers of the old one).
+cuking_status upload_prefix(cuking_ctx *ctx, const TileSpace &tiles, hipStream_t stream) {
+  const uint32_t nb = tiles.num_bands();
+  std::vector<uint64_t> prefix((size_t)nb + 1, 0);
+  for (uint32_t b = 0; b < nb; ++b) prefix[b + 1] = prefix[b] + tiles.band_tiles(b);
+  // Small and pageable: wait until the host buffer may go away.
+  HIP_TRY(hipMemcpyAsync(ctx->band_prefix, prefix.data(), prefix.size() * sizeof(uint64_t),
+                         hipMemcpyHostToDevice, stream));
+  ++ctx->host_syncs;
+  HIP_TRY(hipStreamSynchronize(stream));
+  ctx->prefix_for = tiles;
+  return CUKING_OK;
+}
+
 // Builds planes + band prefix for `sm` in the context workspace.
 cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
                       uint32_t words_per_sample, const uint64_t *d_bit_sets,
@@ -365,33 +397,35 @@ cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
   *tiles_out = tiles;
 
   const size_t need = plane_bytes(geo, v.layout);
-  if (need > ctx->planes_bytes) {
-    // Kernels of earlier calls (possibly on other streams) may still read the
-    // old workspace: wait for the whole device before replacing it.
-    HIP_TRY(hipDeviceSynchronize());
-    if (ctx->planes) HIP_TRY(hipFree(ctx->planes));
-    ctx->planes = nullptr;
-    ctx->planes_bytes = 0;
-    ctx->prepared.valid = false;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->planes), need));
-    ctx->planes_bytes = need;
-  }
+  const uint32_t nb = tiles.num_bands();
+  cuking_status st = ensure_workspace(ctx, need, (size_t)nb + 1);
+  if (st != CUKING_OK) return st;
   // Book-keeping of what the workspace holds, and ordering against kernels on
   // other streams that still read what is about to be overwritten -- the planes
   // AND the band prefix below, so this comes before either is touched.
   const uint32_t all_tiles = (geo.s_stride + 63) / 64;
   const uint32_t t_end = s_tile_end < all_tiles ? s_tile_end : all_tiles;
   cuking_ctx::Prepared &pr = ctx->prepared;
+  const bool new_prefix = !same_tile_space(ctx->prefix_for, tiles);
+  const bool same = same_block(pr, sm, words_per_sample, variant, d_bit_sets);
+  if (ctx->reuse_prepared && same && !new_prefix) {
+    // The host has promised that the bitset behind this pointer is unchanged
+    // since it was converted (cuking_invalidate otherwise): nothing to do when
+    // every tile asked for is there.
+    bool all_there = true;
+    for (uint32_t t = s_tile_begin; t < t_end && all_there; ++t) all_there = pr.tiles[t] != 0;
+    if (all_there) {
+      ++ctx->conversions_skipped;
+      return CUKING_OK;
+    }
+  }
   // Needs ordering: a conversion for another block while anything may still
   // read the old one; a repeated conversion of tiles that kernels enqueued
   // since have read (2); or of tiles whose readers were last ordered behind a
   // different stream (1).  Fresh tiles of the same block have no readers.
   const bool other_stream = pr.ordered_valid && pr.ordered_on != stream;
-  const TileSpace &pf = ctx->prefix_for;
-  const bool new_prefix = pf.tiles_r != tiles.tiles_r || pf.tiles_c != tiles.tiles_c ||
-                          pf.band_rows != tiles.band_rows || pf.diag != tiles.diag;
   bool must_wait = new_prefix && !ctx->readers.empty();
-  if (!same_block(pr, sm, words_per_sample, variant, d_bit_sets)) {
+  if (!same) {
     must_wait = must_wait || !ctx->readers.empty();
     pr.valid = true;
     pr.sm = sm;
@@ -403,31 +437,13 @@ cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
   for (uint32_t t = s_tile_begin; t < t_end; ++t)
     must_wait = must_wait || pr.tiles[t] == 2 || (pr.tiles[t] == 1 && other_stream);
   if (must_wait) {
-    const cuking_status st = wait_for_readers(ctx, stream);
+    st = wait_for_readers(ctx, stream);
     if (st != CUKING_OK) return st;
   }
   for (uint32_t t = s_tile_begin; t < t_end; ++t) pr.tiles[t] = 1;
-  const uint32_t nb = tiles.num_bands();
-  if ((size_t)nb + 1 > ctx->band_prefix_entries) {
-    HIP_TRY(hipDeviceSynchronize());
-    if (ctx->band_prefix) HIP_TRY(hipFree(ctx->band_prefix));
-    ctx->band_prefix = nullptr;
-    ctx->band_prefix_entries = 0;
-    ctx->prefix_for = TileSpace{0, 0, 0, 0};
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->band_prefix),
-                      ((size_t)nb + 1) * sizeof(uint64_t)));
-    ctx->band_prefix_entries = (size_t)nb + 1;
-  }
   if (new_prefix) {
-    std::vector<uint64_t> prefix((size_t)nb + 1, 0);
-    for (uint32_t b = 0; b < nb; ++b)
-      prefix[b + 1] = prefix[b] + tiles.band_tiles(b);
-    // Small and pageable: wait until the host buffer may go away.
-    HIP_TRY(hipMemcpyAsync(ctx->band_prefix, prefix.data(),
-                           prefix.size() * sizeof(uint64_t),
-                           hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    ctx->prefix_for = tiles;
+    st = upload_prefix(ctx, tiles, stream);
+    if (st != CUKING_OK) return st;
   }
 
   if (need == 0) return CUKING_OK;
@@ -457,7 +473,7 @@ cuking_status run_tiled(cuking_ctx *ctx, const cuking_submatrix &sm,
     tile_end = n_tiles;
   }
   if (tile_begin > tile_end || tile_end > n_tiles)
-    return fail(CUKING_ERR_INVALID_ARGUMENT,
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT,
                 "tile range [%llu, %llu) outside [0, %llu)",
                 (unsigned long long)tile_begin, (unsigned long long)tile_end,
                 (unsigned long long)n_tiles);
@@ -521,156 +537,6 @@ cuking_status run_stream(cuking_ctx *ctx, const cuking_submatrix &sm,
 
 extern "C" {
 
-const char *cuking_last_error(void) { return g_last_error.c_str(); }
-uint32_t cuking_abi_version(void) { return CUKING_ABI_VERSION; }
-
-// ---- host-only helpers ----------------------------------------------------
-
-cuking_status cuking_submatrix_init(cuking_submatrix *sm, uint32_t num_samples,
-                                    uint32_t split_factor,
-                                    uint32_t shard_index) {
-  if (sm == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null submatrix");
-  if (split_factor == 0)
-    return fail(CUKING_ERR_INVALID_ARGUMENT, "Invalid split factor");
-  const uint64_t shards = (uint64_t)split_factor * ((uint64_t)split_factor + 1) / 2;
-  if (shard_index >= shards)
-    return fail(CUKING_ERR_INVALID_ARGUMENT, "Invalid shard index");
-  // Row r of the block triangle starts at shard r*k - r(r-1)/2.
-  uint32_t block_i = 0;
-  uint64_t first = 0;
-  while (first + (split_factor - block_i) <= shard_index) {
-    first += split_factor - block_i;
-    ++block_i;
-  }
-  const uint32_t block_j = block_i + (uint32_t)(shard_index - first);
-  const uint64_t size = ceil_div(num_samples, split_factor);
-  auto clamp = [&](uint64_t x) {
-    return (uint32_t)std::min<uint64_t>(x, num_samples);
-  };
-  sm->i_begin = clamp(block_i * size);
-  sm->i_end = clamp(block_i * size + size);
-  sm->j_begin = clamp(block_j * size);
-  sm->j_end = clamp(block_j * size + size);
-  return CUKING_OK;
-}
-
-uint32_t cuking_submatrix_num_rows(const cuking_submatrix *sm) { return sm_num_rows(*sm); }
-uint32_t cuking_submatrix_num_cols(const cuking_submatrix *sm) { return sm_num_cols(*sm); }
-uint32_t cuking_submatrix_num_samples(const cuking_submatrix *sm) { return sm_num_samples(*sm); }
-uint32_t cuking_submatrix_contains(const cuking_submatrix *sm, uint32_t index) {
-  return sm_contains(*sm, index) ? 1u : 0u;
-}
-uint32_t cuking_submatrix_sample_offset(const cuking_submatrix *sm, uint32_t index) {
-  return sm_sample_offset(*sm, index);
-}
-
-uint64_t cuking_submatrix_num_pairs(const cuking_submatrix *sm) {
-  const uint64_t r = sm_num_rows(*sm), c = sm_num_cols(*sm);
-  if (sm_is_diag(*sm)) return r * (r - (r ? 1 : 0)) / 2;
-  // Off-diagonal blocks lie strictly above the diagonal: every (i, j) counts.
-  uint64_t n = 0;
-  if (sm->j_begin >= sm->i_end) return r * c;
-  for (uint32_t i = sm->i_begin; i < sm->i_end; ++i) {
-    const uint32_t lo = std::max(sm->j_begin, i + 1);
-    if (lo < sm->j_end) n += sm->j_end - lo;
-  }
-  return n;
-}
-
-uint32_t cuking_padded_sites(uint32_t num_sites) { return round_up(num_sites, 32u); }
-uint32_t cuking_words_per_sample(uint32_t num_sites) {
-  return 2u * ceil_div(cuking_padded_sites(num_sites), 64u);
-}
-uint64_t cuking_bytes_per_pair(uint32_t words_per_sample) {
-  return 2ull * words_per_sample * sizeof(uint64_t);
-}
-
-cuking_status cuking_pack_host(const cuking_submatrix *sm,
-                               uint32_t words_per_sample, uint64_t *bit_set,
-                               const int64_t *row_idx, const int64_t *col_idx,
-                               const int32_t *n_alt_alleles,
-                               size_t num_triples) {
-  cuking_status st = check_block(sm, words_per_sample);
-  if (st != CUKING_OK) return st;
-  const uint32_t plane_words = words_per_sample / 2;
-  const uint64_t plane_bits = (uint64_t)plane_words * 64;
-  auto clear_bit = [](uint64_t *plane, uint64_t index) {
-    __atomic_and_fetch(plane + (index >> 6), ~(1ull << (index & 63)),
-                       __ATOMIC_RELAXED);
-  };
-  for (size_t t = 0; t < num_triples; ++t) {
-    const int64_t col = col_idx[t];
-    if (col < 0 || col > 0xFFFFFFFFll || !sm_contains(*sm, (uint32_t)col))
-      continue;
-    const int64_t row = row_idx[t];
-    if (row < 0 || (uint64_t)row >= plane_bits)
-      return fail(CUKING_ERR_INVALID_ARGUMENT,
-                  "row_idx %lld outside the %llu padded sites", (long long)row,
-                  (unsigned long long)plane_bits);
-    uint64_t *het = bit_set + (uint64_t)sm_sample_offset(*sm, (uint32_t)col) *
-                                  words_per_sample;
-    uint64_t *hom = het + plane_words;
-    switch (n_alt_alleles[t]) {
-      case 0:
-        clear_bit(het, (uint64_t)row);
-        clear_bit(hom, (uint64_t)row);
-        break;
-      case 1:
-        clear_bit(hom, (uint64_t)row);
-        break;
-      case 2:
-        clear_bit(het, (uint64_t)row);
-        break;
-      default:
-        return fail(CUKING_ERR_FAILED_PRECONDITION,
-                    "Invalid value for n_alt_alleles (%d) encountered",
-                    n_alt_alleles[t]);
-    }
-  }
-  return CUKING_OK;
-}
-
-cuking_status cuking_narrow_triples(const cuking_submatrix *sm, uint32_t words_per_sample,
-                                    const int64_t *row_idx, const int64_t *col_idx,
-                                    const int32_t *n_alt_alleles, size_t num_triples,
-                                    uint32_t *site, uint32_t *sample_alt,
-                                    size_t *num_out) {
-  cuking_status st = check_block(sm, words_per_sample);
-  if (st != CUKING_OK) return st;
-  if (num_out == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null out pointer");
-  *num_out = 0;
-  if (cuking_submatrix_num_samples(sm) > 0x3FFFFFFFu)
-    return fail(CUKING_ERR_INVALID_ARGUMENT, "block holds more than 2^30 samples");
-  const uint64_t plane_bits = (uint64_t)(words_per_sample / 2) * 64;
-  size_t w = 0;
-  for (size_t t = 0; t < num_triples; ++t) {
-    const int64_t col = col_idx[t];
-    if (col < 0 || col > 0xFFFFFFFFll || !sm_contains(*sm, (uint32_t)col)) continue;
-    const int64_t row = row_idx[t];
-    if (row < 0 || (uint64_t)row >= plane_bits)
-      return fail(CUKING_ERR_INVALID_ARGUMENT,
-                  "row_idx %lld outside the %llu padded sites", (long long)row,
-                  (unsigned long long)plane_bits);
-    const int32_t g = n_alt_alleles[t];
-    if (g < 0 || g > 2)
-      return fail(CUKING_ERR_FAILED_PRECONDITION,
-                  "Invalid value for n_alt_alleles (%d) encountered", g);
-    site[w] = (uint32_t)row;
-    sample_alt[w] = sm_sample_offset(*sm, (uint32_t)col) | ((uint32_t)g << 30);
-    ++w;
-  }
-  *num_out = w;
-  return CUKING_OK;
-}
-
-void cuking_sort_results(cuking_result *results, size_t num_results) {
-  std::sort(results, results + num_results,
-            [](const cuking_result &a, const cuking_result &b) {
-              return std::tie(a.sample_i, a.sample_j, a.kin) <
-                     std::tie(b.sample_i, b.sample_j, b.kin);
-            });
-}
-
 // ---- context and memory ---------------------------------------------------
 
 int cuking_device_count(void) {
@@ -680,20 +546,20 @@ int cuking_device_count(void) {
 }
 
 cuking_status cuking_ctx_create(int device, cuking_ctx **out) {
-  if (out == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null out pointer");
+  if (out == nullptr) return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null out pointer");
   *out = nullptr;
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n == 0)
-    return fail(CUKING_ERR_DEVICE,
+    return cuking_fail(CUKING_ERR_DEVICE,
                 "no HIP device available (%s); this library has no CPU path",
                 e == hipSuccess ? "0 devices" : hipGetErrorString(e));
   if (device < 0 || device >= n)
-    return fail(CUKING_ERR_INVALID_ARGUMENT, "device %d outside [0, %d)", device, n);
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "device %d outside [0, %d)", device, n);
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    return fail(CUKING_ERR_DEVICE,
+    return cuking_fail(CUKING_ERR_DEVICE,
                 "device %d is %s; this library only carries gfx950 code",
                 device, prop.gcnArchName);
   HIP_TRY(hipSetDevice(device));
@@ -735,9 +601,9 @@ void cuking_ctx_destroy(cuking_ctx *ctx) {
 }
 
 cuking_status cuking_ctx_set_kernel(cuking_ctx *ctx, cuking_kernel kernel) {
-  if (ctx == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null context");
+  if (ctx == nullptr) return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null context");
   if (kernel != CUKING_KERNEL_TILED && kernel != CUKING_KERNEL_STREAM)
-    return fail(CUKING_ERR_INVALID_ARGUMENT, "unknown kernel %d", (int)kernel);
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "unknown kernel %d", (int)kernel);
   ctx->kernel = kernel;
   return CUKING_OK;
 }
@@ -745,23 +611,23 @@ cuking_status cuking_ctx_set_kernel(cuking_ctx *ctx, cuking_kernel kernel) {
 cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
                                     int64_t value) {
   if (ctx == nullptr || key == nullptr)
-    return fail(CUKING_ERR_INVALID_ARGUMENT, "null argument");
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null argument");
   if (strcmp(key, "variant") == 0) {
     if (value < 0 || value >= kNumTiledVariants)
-      return fail(CUKING_ERR_INVALID_ARGUMENT, "variant outside [0, %d)",
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "variant outside [0, %d)",
                   kNumTiledVariants);
     ctx->variant = (int)value;
     return CUKING_OK;
   }
   if (strcmp(key, "band_rows") == 0) {
     if (value < 0 || value > 64)
-      return fail(CUKING_ERR_INVALID_ARGUMENT, "band_rows outside [0, 64]");
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "band_rows outside [0, 64]");
     ctx->band_rows = (uint32_t)value;
     return CUKING_OK;
   }
   if (strcmp(key, "split_wgs") == 0) {  // 0 = never split the remainder
     if (value < 0 || value > 4096)
-      return fail(CUKING_ERR_INVALID_ARGUMENT, "split_wgs outside [0, 4096]");
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "split_wgs outside [0, 4096]");
     if ((uint32_t)value != ctx->split_wgs) {
       // slabs are sized by the workgroup count
       HIP_TRY(hipDeviceSynchronize());
@@ -772,35 +638,41 @@ cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
     return CUKING_OK;
   }
   if (strcmp(key, "max_launch_blocks") == 0) {  // test hook, process-wide
-    if (value < 0) return fail(CUKING_ERR_INVALID_ARGUMENT, "negative block cap");
+    if (value < 0) return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "negative block cap");
     set_max_blocks_per_launch((uint64_t)value);
     return CUKING_OK;
   }
   if (strcmp(key, "dyn_tail_tiles") == 0) {  // 0 = never; tests lower it
     if (value < 0 || value > 0x7FFFFFFF)
-      return fail(CUKING_ERR_INVALID_ARGUMENT, "dyn_tail_tiles outside [0, 2^31)");
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "dyn_tail_tiles outside [0, 2^31)");
     ctx->dyn_tail_tiles = (uint32_t)value;
     return CUKING_OK;
   }
   if (strcmp(key, "xcd_swizzle") == 0) {
     if (value < 0 || value > 2)
-      return fail(CUKING_ERR_INVALID_ARGUMENT, "xcd_swizzle outside [0, 2]");
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "xcd_swizzle outside [0, 2]");
     ctx->xcd_swizzle = (int)value;
     return CUKING_OK;
   }
   if (strcmp(key, "counts_mode") == 0) {
     if (value < -1 || value > 1)
-      return fail(CUKING_ERR_INVALID_ARGUMENT, "counts_mode outside [-1, 1]");
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "counts_mode outside [-1, 1]");
     ctx->counts_mode = (int)value;
     return CUKING_OK;
   }
-  return fail(CUKING_ERR_INVALID_ARGUMENT, "unknown option %s", key);
+  if (strcmp(key, "reuse_prepared") == 0) {
+    if (value < 0 || value > 1)
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "reuse_prepared outside [0, 1]");
+    ctx->reuse_prepared = value != 0;
+    return CUKING_OK;
+  }
+  return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "unknown option %s", key);
 }
 
 cuking_status cuking_device_alloc(cuking_ctx *ctx, size_t bytes, void **d_ptr) {
   cuking_status st = bind(ctx);
   if (st != CUKING_OK) return st;
-  if (d_ptr == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null out pointer");
+  if (d_ptr == nullptr) return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null out pointer");
   *d_ptr = nullptr;
   if (bytes == 0) return CUKING_OK;
   HIP_TRY(hipMalloc(d_ptr, bytes));
@@ -853,7 +725,7 @@ cuking_status cuking_stream_synchronize(cuking_ctx *ctx, void *stream) {
 cuking_status cuking_stream_create(cuking_ctx *ctx, void **stream) {
   cuking_status st = bind(ctx);
   if (st != CUKING_OK) return st;
-  if (stream == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null out pointer");
+  if (stream == nullptr) return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null out pointer");
   hipStream_t s = nullptr;
   HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   *stream = s;
@@ -881,7 +753,7 @@ cuking_status cuking_stream_destroy(cuking_ctx *ctx, void *stream) {
 cuking_status cuking_host_alloc(cuking_ctx *ctx, size_t bytes, void **ptr) {
   cuking_status st = bind(ctx);
   if (st != CUKING_OK) return st;
-  if (ptr == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null out pointer");
+  if (ptr == nullptr) return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null out pointer");
   *ptr = nullptr;
   if (bytes == 0) return CUKING_OK;
   HIP_TRY(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
@@ -906,11 +778,11 @@ cuking_status cuking_pack_device(cuking_ctx *ctx, const cuking_submatrix *sm,
                                  void *stream) {
   cuking_status st = bind(ctx);
   if (st != CUKING_OK) return st;
-  st = check_block(sm, words_per_sample);
+  st = cuking_check_block(sm, words_per_sample);
   if (st != CUKING_OK) return st;
   if (num_triples &&
       (!d_bit_set || !d_row_idx || !d_col_idx || !d_n_alt_alleles || !d_status))
-    return fail(CUKING_ERR_INVALID_ARGUMENT, "null device pointer");
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null device pointer");
   HIP_TRY(launch_pack(*sm, words_per_sample, d_bit_set, d_row_idx, d_col_idx,
                       d_n_alt_alleles, num_triples, d_status,
                       (hipStream_t)stream));
@@ -924,10 +796,10 @@ cuking_status cuking_pack_device_compact(cuking_ctx *ctx, const cuking_submatrix
                                          uint32_t *d_status, void *stream) {
   cuking_status st = bind(ctx);
   if (st != CUKING_OK) return st;
-  st = check_block(sm, words_per_sample);
+  st = cuking_check_block(sm, words_per_sample);
   if (st != CUKING_OK) return st;
   if (num_triples && (!d_bit_set || !d_site || !d_sample_alt || !d_status))
-    return fail(CUKING_ERR_INVALID_ARGUMENT, "null device pointer");
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null device pointer");
   HIP_TRY(launch_pack_compact(words_per_sample, sm_num_samples(*sm), d_bit_set, d_site,
                               d_sample_alt, num_triples, d_status, (hipStream_t)stream));
   return CUKING_OK;
@@ -936,7 +808,7 @@ cuking_status cuking_pack_device_compact(cuking_ctx *ctx, const cuking_submatrix
 cuking_status cuking_event_create(cuking_ctx *ctx, void **event) {
   cuking_status st = bind(ctx);
   if (st != CUKING_OK) return st;
-  if (event == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null out pointer");
+  if (event == nullptr) return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null out pointer");
   hipEvent_t e = nullptr;
   HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   *event = e;
@@ -980,13 +852,13 @@ cuking_status cuking_tile_bounds(const cuking_ctx *ctx,
                                  const cuking_submatrix *sm, uint64_t tile,
                                  uint32_t *row_begin, uint32_t *row_end,
                                  uint32_t *col_begin, uint32_t *col_end) {
-  cuking_status st = check_block(sm, 2);
+  cuking_status st = cuking_check_block(sm, 2);
   if (st != CUKING_OK) return st;
   const TiledVariant &v = tiled_variant(ctx ? ctx->variant : default_variant());
   const PlaneGeometry g = make_geometry(*sm, 2, v);
   const TileSpace ts = make_tiles(g, v, ctx ? ctx->band_rows : 0);
   if (g.num_rows == 0 || g.num_cols == 0 || tile >= total_tiles(ts))
-    return fail(CUKING_ERR_INVALID_ARGUMENT, "tile index out of range");
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "tile index out of range");
   uint32_t b = 0;
   uint64_t first = 0;
   while (first + ts.band_tiles(b) <= tile) first += ts.band_tiles(b++);
@@ -1004,14 +876,18 @@ cuking_status cuking_tile_bounds(const cuking_ctx *ctx,
 cuking_status cuking_ctx_get_option(const cuking_ctx *ctx, const char *key,
                                     int64_t *value) {
   if (ctx == nullptr || key == nullptr || value == nullptr)
-    return fail(CUKING_ERR_INVALID_ARGUMENT, "null argument");
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null argument");
   if (strcmp(key, "variant") == 0) *value = ctx->variant;
   else if (strcmp(key, "split_wgs") == 0) *value = ctx->split_wgs;
   else if (strcmp(key, "band_rows") == 0) *value = ctx->band_rows;
   else if (strcmp(key, "counts_mode") == 0) *value = ctx->counts_mode;
   else if (strcmp(key, "xcd_swizzle") == 0) *value = ctx->xcd_swizzle;
   else if (strcmp(key, "dyn_tail_tiles") == 0) *value = ctx->dyn_tail_tiles;
-  else return fail(CUKING_ERR_INVALID_ARGUMENT, "unknown option %s", key);
+  else if (strcmp(key, "reuse_prepared") == 0) *value = ctx->reuse_prepared ? 1 : 0;
+  else if (strcmp(key, "workspace_allocations") == 0) *value = (int64_t)ctx->workspace_allocations;
+  else if (strcmp(key, "host_syncs") == 0) *value = (int64_t)ctx->host_syncs;
+  else if (strcmp(key, "conversions_skipped") == 0) *value = (int64_t)ctx->conversions_skipped;
+  else return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "unknown option %s", key);
   return CUKING_OK;
 }
 
@@ -1024,10 +900,10 @@ const char *cuking_variant_name(int variant) {
 static cuking_status check_compute_args(const cuking_submatrix *sm,
                                         uint32_t words_per_sample,
                                         const uint64_t *d_bit_sets) {
-  cuking_status st = check_block(sm, words_per_sample);
+  cuking_status st = cuking_check_block(sm, words_per_sample);
   if (st != CUKING_OK) return st;
   if (sm_num_samples(*sm) != 0 && d_bit_sets == nullptr)
-    return fail(CUKING_ERR_INVALID_ARGUMENT, "null bitset pointer");
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null bitset pointer");
   return CUKING_OK;
 }
 
@@ -1043,7 +919,7 @@ cuking_status cuking_compute_king(cuking_ctx *ctx, const cuking_submatrix *sm,
   st = check_compute_args(sm, words_per_sample, d_bit_sets);
   if (st != CUKING_OK) return st;
   if (!d_result_index || !d_result_overflow || (max_results && !d_results))
-    return fail(CUKING_ERR_INVALID_ARGUMENT, "null result pointer");
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null result pointer");
   if (sm_num_rows(*sm) == 0 || sm_num_cols(*sm) == 0) return CUKING_OK;
   if (ctx->kernel == CUKING_KERNEL_STREAM)
     return run_stream(ctx, *sm, words_per_sample, d_bit_sets, kin_threshold,
@@ -1064,10 +940,10 @@ cuking_status cuking_compute_king_tiles(
   st = check_compute_args(sm, words_per_sample, d_bit_sets);
   if (st != CUKING_OK) return st;
   if (!d_result_index || !d_result_overflow || (max_results && !d_results))
-    return fail(CUKING_ERR_INVALID_ARGUMENT, "null result pointer");
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null result pointer");
   if (sm_num_rows(*sm) == 0 || sm_num_cols(*sm) == 0) {
     if (tile_begin != 0 || tile_end != 0)
-      return fail(CUKING_ERR_INVALID_ARGUMENT, "empty block has no tiles");
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "empty block has no tiles");
     return CUKING_OK;
   }
   return run_tiled(ctx, *sm, words_per_sample, d_bit_sets, tile_begin, tile_end,
@@ -1080,11 +956,11 @@ static cuking_status tile_span(const cuking_submatrix &sm, uint32_t tile,
                                uint32_t begin, uint32_t end, const char *what,
                                uint32_t *t0, uint32_t *t1) {
   if (begin < sm.i_begin || end > sm.i_end || begin > end)
-    return fail(CUKING_ERR_INVALID_ARGUMENT, "%s range [%u, %u) outside the block",
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "%s range [%u, %u) outside the block",
                 what, begin, end);
   const uint32_t b = begin - sm.i_begin, e = end - sm.i_begin;
   if (b % tile != 0 || (e % tile != 0 && end != sm.i_end))
-    return fail(CUKING_ERR_INVALID_ARGUMENT,
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT,
                 "%s range [%u, %u) is not aligned to the %u-sample tile edge", what,
                 begin, end, tile);
   *t0 = b / tile;
@@ -1102,7 +978,7 @@ cuking_status cuking_prepare_samples(cuking_ctx *ctx, const cuking_submatrix *sm
   st = check_compute_args(sm, words_per_sample, d_bit_sets);
   if (st != CUKING_OK) return st;
   if (!sm_is_diag(*sm))
-    return fail(CUKING_ERR_INVALID_ARGUMENT,
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT,
                 "staged preparation needs a diagonal block (rows == columns)");
   const uint32_t tile = tiled_variant(effective_variant(ctx, words_per_sample)).tile;
   uint32_t t0, t1;
@@ -1127,10 +1003,10 @@ cuking_status cuking_compute_king_rect(
   st = check_compute_args(sm, words_per_sample, d_bit_sets);
   if (st != CUKING_OK) return st;
   if (!sm_is_diag(*sm))
-    return fail(CUKING_ERR_INVALID_ARGUMENT,
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT,
                 "rectangle launches need a diagonal block (rows == columns)");
   if (!d_result_index || !d_result_overflow || (max_results && !d_results))
-    return fail(CUKING_ERR_INVALID_ARGUMENT, "null result pointer");
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null result pointer");
   const TiledVariant &v = tiled_variant(effective_variant(ctx, words_per_sample));
   const PlaneGeometry geo = make_geometry(*sm, words_per_sample, v);
   // Rectangles of a diagonal block contain slots below the diagonal that leave
@@ -1144,7 +1020,7 @@ cuking_status cuking_compute_king_rect(
   const int variant = effective_variant(ctx, words_per_sample);
   if (ctx->planes == nullptr || ctx->planes_bytes < need ||
       !same_block(ctx->prepared, *sm, words_per_sample, variant, d_bit_sets))
-    return fail(CUKING_ERR_FAILED_PRECONDITION,
+    return cuking_fail(CUKING_ERR_FAILED_PRECONDITION,
                 "cuking_prepare_samples() has not been called for this block "
                 "(or the workspace has been converted for another one since)");
   uint32_t r0, r1, c0, c1;
@@ -1155,7 +1031,7 @@ cuking_status cuking_compute_king_rect(
   if (r0 == r1 || c0 == c1) return CUKING_OK;
   if (row_step == 0) row_step = v.tile;
   if (row_step % v.tile != 0)
-    return fail(CUKING_ERR_INVALID_ARGUMENT,
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT,
                 "row_step %u is not a multiple of the %u-sample tile edge", row_step,
                 v.tile);
   const uint32_t stride = row_step / v.tile;
@@ -1171,12 +1047,12 @@ cuking_status cuking_compute_king_rect(
     };
     for (uint32_t r = r0; r < r1; r += stride)
       if (!converted(r))
-        return fail(CUKING_ERR_FAILED_PRECONDITION,
+        return cuking_fail(CUKING_ERR_FAILED_PRECONDITION,
                     "row samples from %u on have not been prepared",
                     sm->i_begin + r * v.tile);
     for (uint32_t c = c0; c < c1; ++c)
       if (!converted(c))
-        return fail(CUKING_ERR_FAILED_PRECONDITION,
+        return cuking_fail(CUKING_ERR_FAILED_PRECONDITION,
                     "column samples from %u on have not been prepared",
                     sm->i_begin + c * v.tile);
   }
@@ -1226,6 +1102,66 @@ cuking_status cuking_compute_king_rect(
   return CUKING_OK;
 }
 
+cuking_status cuking_ctx_reserve(cuking_ctx *ctx, const cuking_submatrix *sm,
+                                 uint32_t words_per_sample, void *const *streams,
+                                 size_t num_streams) {
+  cuking_status st = bind(ctx);
+  if (st != CUKING_OK) return st;
+  st = cuking_check_block(sm, words_per_sample);
+  if (st != CUKING_OK) return st;
+  if (num_streams != 0 && streams == nullptr)
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null stream list");
+  if (sm_num_rows(*sm) == 0 || sm_num_cols(*sm) == 0) return CUKING_OK;
+  const int variant = effective_variant(ctx, words_per_sample);
+  const TiledVariant &v = tiled_variant(variant);
+  const PlaneGeometry geo = make_geometry(*sm, words_per_sample, v);
+  const TileSpace tiles = make_tiles(geo, v, ctx->band_rows);
+  st = ensure_workspace(ctx, plane_bytes(geo, v.layout), (size_t)tiles.num_bands() + 1);
+  if (st != CUKING_OK) return st;
+  if (!same_tile_space(ctx->prefix_for, tiles)) {
+    // (nothing may be reading another block's prefix: the caller reserves
+    //  before it enqueues work for this block)
+    if (!ctx->readers.empty()) {
+      ++ctx->host_syncs;
+      HIP_TRY(hipDeviceSynchronize());
+    }
+    st = upload_prefix(ctx, tiles, nullptr);
+    if (st != CUKING_OK) return st;
+  }
+  if (num_streams > 8)
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "at most 8 streams per context can be reserved");
+  if (ctx->split_wgs != 0 && ctx->variant == kMfmaVariant) {
+    // (the slab cache holds 8 streams and drops ALL of them when a ninth comes:
+    //  make room now rather than lose a slab reserved a moment ago)
+    size_t missing = 0;
+    for (size_t k = 0; k < num_streams; ++k) {
+      bool have = false;
+      for (auto &e : ctx->split_scratch) have = have || e.first == (hipStream_t)streams[k];
+      missing += have ? 0 : 1;
+    }
+    if (missing != 0 && ctx->split_scratch.size() + missing > 8) {
+      ++ctx->host_syncs;
+      HIP_TRY(hipDeviceSynchronize());
+      for (auto &e : ctx->split_scratch) (void)hipFree(e.second);
+      ctx->split_scratch.clear();
+    }
+  }
+  for (size_t k = 0; k < num_streams; ++k) {
+    uint32_t *scratch, *counters;
+    st = split_scratch_for(ctx, (hipStream_t)streams[k], &scratch, &counters);
+    if (st != CUKING_OK) return st;
+  }
+  return CUKING_OK;
+}
+
+cuking_status cuking_invalidate(cuking_ctx *ctx) {
+  if (ctx == nullptr) return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null context");
+  // The next conversion treats the workspace as another block's: it is ordered
+  // behind every kernel that may still read it.
+  ctx->prepared.valid = false;
+  return CUKING_OK;
+}
+
 cuking_status cuking_compute_counts(cuking_ctx *ctx, const cuking_submatrix *sm,
                                     uint32_t words_per_sample,
                                     const uint64_t *d_bit_sets,
@@ -1236,7 +1172,7 @@ cuking_status cuking_compute_counts(cuking_ctx *ctx, const cuking_submatrix *sm,
   if (st != CUKING_OK) return st;
   if (sm_num_rows(*sm) == 0 || sm_num_cols(*sm) == 0) return CUKING_OK;
   if (d_counts == nullptr)
-    return fail(CUKING_ERR_INVALID_ARGUMENT, "null counts pointer");
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null counts pointer");
   if (ctx->kernel == CUKING_KERNEL_STREAM)
     return run_stream(ctx, *sm, words_per_sample, d_bit_sets, 0.f, 0, nullptr,
                       nullptr, nullptr, d_counts, (hipStream_t)stream);
@@ -1247,13 +1183,13 @@ cuking_status cuking_compute_counts(cuking_ctx *ctx, const cuking_submatrix *sm,
 // ---- timing ---------------------------------------------------------------
 
 cuking_status cuking_timing_enable(cuking_ctx *ctx, int enabled) {
-  if (ctx == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null context");
+  if (ctx == nullptr) return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null context");
   ctx->timing = enabled != 0;
   return CUKING_OK;
 }
 
 cuking_status cuking_timing_reset(cuking_ctx *ctx) {
-  if (ctx == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null context");
+  if (ctx == nullptr) return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null context");
   ctx->king_timer.used = 0;
   ctx->prepare_timer.used = 0;
   return CUKING_OK;
@@ -1316,9 +1252,9 @@ cuking_status cuking_clock_probe(cuking_ctx *ctx, uint64_t microseconds,
                                  uint64_t *d_ticks, void *stream) {
   cuking_status st = bind(ctx);
   if (st != CUKING_OK) return st;
-  if (d_ticks == nullptr) return fail(CUKING_ERR_INVALID_ARGUMENT, "null out pointer");
+  if (d_ticks == nullptr) return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null out pointer");
   if (microseconds == 0 || microseconds > 60ull * 1000 * 1000)
-    return fail(CUKING_ERR_INVALID_ARGUMENT, "probe time outside (0, 60 s]");
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "probe time outside (0, 60 s]");
   HIP_TRY(launch_clock_probe(microseconds, d_ticks, (hipStream_t)stream));
   return CUKING_OK;
 }
@@ -1334,13 +1270,13 @@ cuking_status cuking_synth_bitset(cuking_ctx *ctx, uint64_t seed,
   cuking_status st = bind(ctx);
   if (st != CUKING_OK) return st;
   if (sample_end < sample_begin)
-    return fail(CUKING_ERR_INVALID_ARGUMENT, "sample range reversed");
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "sample range reversed");
   if (words_per_sample != cuking_words_per_sample(num_sites))
-    return fail(CUKING_ERR_INVALID_ARGUMENT,
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT,
                 "words_per_sample %u does not match %u sites", words_per_sample,
                 num_sites);
   if (sample_end > sample_begin && (!d_kind || !d_pa || !d_pb || !d_bit_set))
-    return fail(CUKING_ERR_INVALID_ARGUMENT, "null device pointer");
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null device pointer");
   HIP_TRY(launch_synth(seed, d_kind, d_pa, d_pb, sample_begin, sample_end,
                        num_sites, words_per_sample, d_bit_set,
                        (hipStream_t)stream));

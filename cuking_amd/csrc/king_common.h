@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "cuking_amd.h"
+#include "king_submatrix.h"
 
 namespace cuking {
 
@@ -240,30 +241,6 @@ hipError_t launch_synth(uint64_t seed, const uint32_t *d_kind,
 
 hipError_t launch_clock_probe(uint64_t microseconds, uint64_t *d_out,
                               hipStream_t stream);
-
-// Submatrix helpers usable on both sides (cuking.cu:154-175).
-__host__ __device__ inline uint32_t sm_num_rows(const cuking_submatrix &s) {
-  return s.i_end - s.i_begin;
-}
-__host__ __device__ inline uint32_t sm_num_cols(const cuking_submatrix &s) {
-  return s.j_end - s.j_begin;
-}
-__host__ __device__ inline bool sm_is_diag(const cuking_submatrix &s) {
-  return s.i_begin == s.j_begin;
-}
-__host__ __device__ inline uint32_t sm_num_samples(const cuking_submatrix &s) {
-  return sm_is_diag(s) ? sm_num_rows(s) : sm_num_rows(s) + sm_num_cols(s);
-}
-__host__ __device__ inline bool sm_contains(const cuking_submatrix &s,
-                                            uint32_t index) {
-  return (s.i_begin <= index && index < s.i_end) ||
-         (s.j_begin <= index && index < s.j_end);
-}
-__host__ __device__ inline uint32_t sm_sample_offset(const cuking_submatrix &s,
-                                                     uint32_t index) {
-  return index < s.i_end ? index - s.i_begin
-                         : (s.i_end - s.i_begin) + (index - s.j_begin);
-}
 
 }  // namespace cuking
 

@@ -1,0 +1,211 @@
+// Host-only half of the C ABI (include/cuking_amd.h): Submatrix arithmetic,
+// bitset sizing, the host pack with its relaxed atomics, the narrowing step of
+// the device pack, the record sort, the per-thread error message.  Plain C++
+// (no HIP): hipcc compiles it into libcuking_amd.so, and the sanitizer tests
+// compile the same file with g++ -fsanitize=thread / address so that the code
+// that runs on many reader threads is instrumented (tests/test_cli.py).
+#include "king_host.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <tuple>
+
+#include "king_submatrix.h"
+
+using namespace cuking;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+uint32_t ceil_div(uint32_t a, uint32_t b) {
+  return (uint32_t)(((uint64_t)a + b - 1) / b);
+}
+uint32_t round_up(uint32_t a, uint32_t b) { return ceil_div(a, b) * b; }
+
+}  // namespace
+
+cuking_status cuking_fail(cuking_status code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+cuking_status cuking_check_block(const cuking_submatrix *sm,
+                          uint32_t words_per_sample) {
+  if (sm == nullptr) return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null submatrix");
+  if (sm->i_end < sm->i_begin || sm->j_end < sm->j_begin)
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "submatrix ranges are reversed");
+  if (!sm_is_diag(*sm) && sm->j_begin < sm->i_end && sm_num_rows(*sm) != 0 &&
+      sm_num_cols(*sm) != 0)
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT,
+                "row and column ranges must be identical or disjoint with "
+                "rows first");
+  if (sm_is_diag(*sm) && sm->i_end != sm->j_end)
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT,
+                "a diagonal block needs identical row and column ranges");
+  if (words_per_sample == 0 || (words_per_sample & 1))
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT,
+                "words_per_sample must be a positive even number");
+  return CUKING_OK;
+}
+
+extern "C" {
+
+const char *cuking_last_error(void) { return g_last_error.c_str(); }
+uint32_t cuking_abi_version(void) { return CUKING_ABI_VERSION; }
+
+// ---- host-only helpers ----------------------------------------------------
+
+cuking_status cuking_submatrix_init(cuking_submatrix *sm, uint32_t num_samples,
+                                    uint32_t split_factor,
+                                    uint32_t shard_index) {
+  if (sm == nullptr) return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null submatrix");
+  if (split_factor == 0)
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "Invalid split factor");
+  const uint64_t shards = (uint64_t)split_factor * ((uint64_t)split_factor + 1) / 2;
+  if (shard_index >= shards)
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "Invalid shard index");
+  // Row r of the block triangle starts at shard r*k - r(r-1)/2.
+  uint32_t block_i = 0;
+  uint64_t first = 0;
+  while (first + (split_factor - block_i) <= shard_index) {
+    first += split_factor - block_i;
+    ++block_i;
+  }
+  const uint32_t block_j = block_i + (uint32_t)(shard_index - first);
+  const uint64_t size = ceil_div(num_samples, split_factor);
+  auto clamp = [&](uint64_t x) {
+    return (uint32_t)std::min<uint64_t>(x, num_samples);
+  };
+  sm->i_begin = clamp(block_i * size);
+  sm->i_end = clamp(block_i * size + size);
+  sm->j_begin = clamp(block_j * size);
+  sm->j_end = clamp(block_j * size + size);
+  return CUKING_OK;
+}
+
+uint32_t cuking_submatrix_num_rows(const cuking_submatrix *sm) { return sm_num_rows(*sm); }
+uint32_t cuking_submatrix_num_cols(const cuking_submatrix *sm) { return sm_num_cols(*sm); }
+uint32_t cuking_submatrix_num_samples(const cuking_submatrix *sm) { return sm_num_samples(*sm); }
+uint32_t cuking_submatrix_contains(const cuking_submatrix *sm, uint32_t index) {
+  return sm_contains(*sm, index) ? 1u : 0u;
+}
+uint32_t cuking_submatrix_sample_offset(const cuking_submatrix *sm, uint32_t index) {
+  return sm_sample_offset(*sm, index);
+}
+
+uint64_t cuking_submatrix_num_pairs(const cuking_submatrix *sm) {
+  const uint64_t r = sm_num_rows(*sm), c = sm_num_cols(*sm);
+  if (sm_is_diag(*sm)) return r * (r - (r ? 1 : 0)) / 2;
+  // Off-diagonal blocks lie strictly above the diagonal: every (i, j) counts.
+  uint64_t n = 0;
+  if (sm->j_begin >= sm->i_end) return r * c;
+  for (uint32_t i = sm->i_begin; i < sm->i_end; ++i) {
+    const uint32_t lo = std::max(sm->j_begin, i + 1);
+    if (lo < sm->j_end) n += sm->j_end - lo;
+  }
+  return n;
+}
+
+uint32_t cuking_padded_sites(uint32_t num_sites) { return round_up(num_sites, 32u); }
+uint32_t cuking_words_per_sample(uint32_t num_sites) {
+  return 2u * ceil_div(cuking_padded_sites(num_sites), 64u);
+}
+uint64_t cuking_bytes_per_pair(uint32_t words_per_sample) {
+  return 2ull * words_per_sample * sizeof(uint64_t);
+}
+
+cuking_status cuking_pack_host(const cuking_submatrix *sm,
+                               uint32_t words_per_sample, uint64_t *bit_set,
+                               const int64_t *row_idx, const int64_t *col_idx,
+                               const int32_t *n_alt_alleles,
+                               size_t num_triples) {
+  cuking_status st = cuking_check_block(sm, words_per_sample);
+  if (st != CUKING_OK) return st;
+  const uint32_t plane_words = words_per_sample / 2;
+  const uint64_t plane_bits = (uint64_t)plane_words * 64;
+  auto clear_bit = [](uint64_t *plane, uint64_t index) {
+    __atomic_and_fetch(plane + (index >> 6), ~(1ull << (index & 63)),
+                       __ATOMIC_RELAXED);
+  };
+  for (size_t t = 0; t < num_triples; ++t) {
+    const int64_t col = col_idx[t];
+    if (col < 0 || col > 0xFFFFFFFFll || !sm_contains(*sm, (uint32_t)col))
+      continue;
+    const int64_t row = row_idx[t];
+    if (row < 0 || (uint64_t)row >= plane_bits)
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT,
+                  "row_idx %lld outside the %llu padded sites", (long long)row,
+                  (unsigned long long)plane_bits);
+    uint64_t *het = bit_set + (uint64_t)sm_sample_offset(*sm, (uint32_t)col) *
+                                  words_per_sample;
+    uint64_t *hom = het + plane_words;
+    switch (n_alt_alleles[t]) {
+      case 0:
+        clear_bit(het, (uint64_t)row);
+        clear_bit(hom, (uint64_t)row);
+        break;
+      case 1:
+        clear_bit(hom, (uint64_t)row);
+        break;
+      case 2:
+        clear_bit(het, (uint64_t)row);
+        break;
+      default:
+        return cuking_fail(CUKING_ERR_FAILED_PRECONDITION,
+                    "Invalid value for n_alt_alleles (%d) encountered",
+                    n_alt_alleles[t]);
+    }
+  }
+  return CUKING_OK;
+}
+
+cuking_status cuking_narrow_triples(const cuking_submatrix *sm, uint32_t words_per_sample,
+                                    const int64_t *row_idx, const int64_t *col_idx,
+                                    const int32_t *n_alt_alleles, size_t num_triples,
+                                    uint32_t *site, uint32_t *sample_alt,
+                                    size_t *num_out) {
+  cuking_status st = cuking_check_block(sm, words_per_sample);
+  if (st != CUKING_OK) return st;
+  if (num_out == nullptr) return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null out pointer");
+  *num_out = 0;
+  if (cuking_submatrix_num_samples(sm) > 0x3FFFFFFFu)
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "block holds more than 2^30 samples");
+  const uint64_t plane_bits = (uint64_t)(words_per_sample / 2) * 64;
+  size_t w = 0;
+  for (size_t t = 0; t < num_triples; ++t) {
+    const int64_t col = col_idx[t];
+    if (col < 0 || col > 0xFFFFFFFFll || !sm_contains(*sm, (uint32_t)col)) continue;
+    const int64_t row = row_idx[t];
+    if (row < 0 || (uint64_t)row >= plane_bits)
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT,
+                  "row_idx %lld outside the %llu padded sites", (long long)row,
+                  (unsigned long long)plane_bits);
+    const int32_t g = n_alt_alleles[t];
+    if (g < 0 || g > 2)
+      return cuking_fail(CUKING_ERR_FAILED_PRECONDITION,
+                  "Invalid value for n_alt_alleles (%d) encountered", g);
+    site[w] = (uint32_t)row;
+    sample_alt[w] = sm_sample_offset(*sm, (uint32_t)col) | ((uint32_t)g << 30);
+    ++w;
+  }
+  *num_out = w;
+  return CUKING_OK;
+}
+
+void cuking_sort_results(cuking_result *results, size_t num_results) {
+  std::sort(results, results + num_results,
+            [](const cuking_result &a, const cuking_result &b) {
+              return std::tie(a.sample_i, a.sample_j, a.kin) <
+                     std::tie(b.sample_i, b.sample_j, b.kin);
+            });
+}
+
+}  // extern "C"

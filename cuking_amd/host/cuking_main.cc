@@ -274,10 +274,20 @@ void PrintSchedule(const Flags &flags, const cuking_submatrix &sm) {
   std::cout << "{\"world\": " << world << ", \"tile\": " << tile << ", \"num_tiles\": "
             << num_tiles << ", \"stored_samples\": " << stored << ", \"mode\": \""
             << (staged ? "staged" : "simple") << "\", \"tile_ranges\": [";
-  const auto parts = cuking_host::TilePartition(num_tiles, world);
+  // (with --rank_weights the ranges the simple schedule would use; otherwise the
+  //  equal ranges it falls back to when it does not calibrate)
+  const auto parts = flags.rank_weight_values.size() == world
+                         ? cuking_host::WeightedTilePartition(num_tiles, flags.rank_weight_values)
+                         : cuking_host::TilePartition(num_tiles, world);
   for (uint32_t r = 0; r < world; ++r)
     std::cout << (r ? ", " : "") << "[" << parts[r].begin << ", " << parts[r].end << "]";
-  std::cout << "], \"chunks\": [";
+  const uint64_t cal =
+      !flags.calibrate || !flags.rank_weight_values.empty() || world < 2 ? 0
+      : flags.calibration_tiles != 0 && flags.calibration_tiles * world <= num_tiles
+          ? flags.calibration_tiles
+          : cuking_host::CalibrationTiles(num_tiles, world);
+  std::cout << "], \"weighted\": " << (flags.rank_weight_values.size() == world ? "true" : "false")
+            << ", \"calibration_tiles\": " << cal << ", \"chunks\": [";
   const auto chunks = cuking_host::ChunkRanges(stored, tile, flags.bcast_chunks);
   for (size_t c = 0; c < chunks.size(); ++c)
     std::cout << (c ? ", " : "") << "[" << chunks[c].begin << ", " << chunks[c].end << "]";
@@ -350,7 +360,12 @@ Status Run(const Flags &flags) {
     return InvalidArgument("--dump_bitset needs input tables, not --synthetic");
   // (a synthetic cohort is generated on the GPU: from here on it is a bitset
   //  that already sits in device memory, like a device-packed one)
-  const bool pack_on_device = (flags.pack == "device" || synthetic) && !dump_only;
+  // --pack=auto: the device pack wins while the GPU's atomics keep up with the
+  // readers (profiles/r02_pack_pipeline.txt: up to ~32 reader threads feeding one
+  // GPU; beyond that the host's cores pack faster than one GPU's atomic units).
+  const std::string pack_mode =
+      flags.pack != "auto" ? flags.pack : flags.num_reader_threads <= 32 ? "device" : "host";
+  const bool pack_on_device = (pack_mode == "device" || synthetic) && !dump_only;
 
   DeviceBuffers buf;
   std::vector<uint64_t> dump_bits;  // --dump_bitset: plain host memory, no GPU
@@ -391,6 +406,27 @@ Status Run(const Flags &flags) {
     std::cout << "Found " << input_files.size() << " input files." << std::endl;
   }
   const bool device_pack = pack_on_device && !synthetic;  // triples packed by the GPU
+  // Decode tasks: one per (file, row group) when the files are fewer than the
+  // reader threads -- the reference hands out whole files (cuking.cu:550-553),
+  // which caps the decode at one thread per file; a table written with several
+  // row groups decodes on several.  {file, row group or -1 = the whole file}.
+  std::vector<std::pair<size_t, int>> tasks;
+  if (!synthetic) {
+    if (input_files.size() >= flags.num_reader_threads) {
+      for (size_t f = 0; f < input_files.size(); ++f) tasks.emplace_back(f, -1);
+    } else {
+      std::vector<int> groups(input_files.size(), 1);
+      const std::string err = cuking_host::ParallelFor(
+          flags.num_reader_threads, 0, input_files.size(), [&](size_t f) -> std::string {
+            return cuking_host::CountRowGroups(input_files[f].first, &groups[f]);
+          });
+      if (!err.empty()) return FailedPrecondition(err);
+      for (size_t f = 0; f < input_files.size(); ++f) {
+        if (groups[f] <= 1) tasks.emplace_back(f, -1);
+        else for (int g = 0; g < groups[f]; ++g) tasks.emplace_back(f, g);
+      }
+    }
+  }
 
   std::cout << (synthetic ? "Synthesising genotypes on the GPU..." : "Processing Parquet tables...")
             << std::flush;
@@ -448,7 +484,7 @@ Status Run(const Flags &flags) {
     std::promise<void> promise;
     setup_done = promise.get_future().share();
     setup_thread = std::thread([&, promise = std::move(promise)]() mutable {
-      const size_t rings = std::min(flags.num_reader_threads, input_files.size());
+      const size_t rings = std::min(flags.num_reader_threads, tasks.size());
       const uint64_t setup_begin = now_us();
       auto check = [&](cuking_status st) {
         if (st != CUKING_OK && setup_error.empty()) setup_error = cuking_last_error();
@@ -479,10 +515,11 @@ Status Run(const Flags &flags) {
     }
   } joiner{setup_thread};
   const std::string pack_error = cuking_host::ParallelFor(
-      flags.num_reader_threads, 0, input_files.size(), [&](size_t f) -> std::string {
+      flags.num_reader_threads, 0, tasks.size(), [&](size_t task) -> std::string {
+        const size_t f = tasks[task].first;
         cuking_host::Triples t;
         const uint64_t t_begin = now_us();
-        std::string err = cuking_host::ReadTriples(input_files[f].first, &t);
+        std::string err = cuking_host::ReadTriples(input_files[f].first, tasks[task].second, &t);
         if (!err.empty()) return "FAILED_PRECONDITION\n" + err;
         const size_t n = t.row_idx.size();
         const uint64_t t_decoded = now_us();
@@ -510,10 +547,14 @@ Status Run(const Flags &flags) {
         if ((++num_processed & 1023) == 0) std::cout << "." << std::flush;  // :705-708
         return "";
       });
+  // The helper thread owns `packers` and `setup_error` until its promise is
+  // set; a run whose tables are all empty never waited for it inside a reader.
+  if (device_pack) setup_done.wait();
   if (!pack_error.empty()) {
     const size_t nl = pack_error.find('\n');
     return {pack_error.substr(0, nl), pack_error.substr(nl + 1)};
   }
+  if (device_pack && !setup_error.empty()) return {"INTERNAL", setup_error};
   if (dump_only) {
     Done(&sw);
     FILE *f = fopen(flags.dump_bitset.c_str(), "wb");
@@ -522,7 +563,8 @@ Status Run(const Flags &flags) {
     fclose(f);
     if (wrote != bit_set_words) return Unknown("Short write to " + flags.dump_bitset);
     std::cout << "Dumped " << bit_set_words << " words (" << num_triples.load()
-              << " triples) to " << flags.dump_bitset << std::endl;
+              << " triples, " << tasks.size() << " decode tasks) to " << flags.dump_bitset
+              << std::endl;
     return Status::Ok();
   }
   if (device_pack) {
@@ -575,6 +617,12 @@ Status Run(const Flags &flags) {
     in.d_bits_rank0 = static_cast<uint64_t *>(buf.d_bits);
     in.kin_threshold = flags.kin_threshold;
     in.max_results = flags.max_results;
+    in.collectives = flags.collectives;
+    in.rank_weights = flags.rank_weight_values;
+    in.calibrate = flags.calibrate;
+    in.calibration_tiles = flags.calibration_tiles;
+    in.inject_failure_rank = flags.inject_failure_rank;
+    in.inject_failure_phase = flags.inject_failure_phase;
     cuking_host::MultiGpuOutput mg;
     std::string code;
     const std::string err = cuking_host::RunMultiGpu(in, &mg, &code);
@@ -598,6 +646,21 @@ Status Run(const Flags &flags) {
     multi_summary << "], \"rank_results\": [";
     for (size_t r = 0; r < mg.rank_results.size(); ++r)
       multi_summary << (r ? ", " : "") << mg.rank_results[r];
+    multi_summary << "], \"collectives\": \"" << mg.collectives
+                  << "\", \"allocations_after_reserve\": [";
+    for (size_t r = 0; r < mg.rank_allocations_after_reserve.size(); ++r)
+      multi_summary << (r ? ", " : "") << mg.rank_allocations_after_reserve[r];
+    multi_summary << "], \"host_syncs_after_reserve\": [";
+    for (size_t r = 0; r < mg.rank_host_syncs_after_reserve.size(); ++r)
+      multi_summary << (r ? ", " : "") << mg.rank_host_syncs_after_reserve[r];
+    multi_summary << "], \"calibration_tiles\": " << mg.calibration_tiles
+                  << ", \"rank_rates_tiles_per_ms\": [";
+    for (size_t r = 0; r < mg.rank_rates.size(); ++r)
+      multi_summary << (r ? ", " : "") << std::setprecision(4) << mg.rank_rates[r];
+    multi_summary << "], \"rank_tile_ranges\": [";
+    for (size_t r = 0; r < mg.rank_tile_ranges.size(); ++r)
+      multi_summary << (r ? ", " : "") << "[" << mg.rank_tile_ranges[r].first << ", "
+                    << mg.rank_tile_ranges[r].second << "]";
     multi_summary << "]";
     if (buf.host_bits) {
       cuking_host_free(buf.ctx, buf.host_bits);
@@ -675,8 +738,8 @@ Status Run(const Flags &flags) {
             << packer_stats.wait_us.load() * 1e-6 << ", \"narrow\": "
             << packer_stats.narrow_us.load() * 1e-6 << ", \"enqueue\": "
             << packer_stats.enqueue_us.load() * 1e-6 << "}"
-            << ", \"pack\": \"" << (synthetic ? "synthetic" : flags.pack)
-            << "\", \"reader_threads\": "
+            << ", \"pack\": \"" << (synthetic ? "synthetic" : pack_mode)
+            << "\", \"decode_tasks\": " << tasks.size() << ", \"reader_threads\": "
             << flags.num_reader_threads << ", \"read_pack_seconds\": " << read_pack_seconds
             << ", \"triples_per_second\": " << std::setprecision(1)
             << (read_pack_seconds > 0 ? num_triples.load() / read_pack_seconds : 0.0)

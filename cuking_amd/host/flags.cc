@@ -50,12 +50,22 @@ std::string Usage() {
          "  --requester_pays_project=P  accepted for compatibility, unused\n"
          "  --device=D             GPU index (default 0)\n"
          "  --kernel=tiled|stream  device kernel (default tiled)\n"
-         "  --pack=host|device     where triples are packed (default host)\n"
+         "  --pack=host|device|auto  where triples are packed (default auto: device when at "
+         "most 32 reader threads feed the GPU)\n"
          "  --num_gpus=N           share the shard among N GPUs of this node over "
          "RCCL (default 0: one GPU, no RCCL)\n"
          "  --multi_gpu_mode=auto|staged|simple  broadcast overlapped with compute "
          "(diagonal shards) or broadcast then tile ranges\n"
          "  --bcast_chunks=N       pieces the bitset broadcast is cut into (default 8)\n"
+         "  --rank_weights=W0,W1,..  simple schedule: tile ranges in proportion to these "
+         "weights (default: measured by one calibration launch per GPU)\n"
+         "  --calibrate=true|false measure the GPUs' rates before cutting the tile ranges "
+         "(default true; large jobs only)\n"
+         "  --calibration_tiles=N  tiles per GPU in the calibration launch (default 0: about "
+         "2 % of a GPU's share)\n"
+         "  --collectives=rccl|loopback  loopback is for tests: the ranks of --num_gpus=N "
+         "share ONE GPU, copies instead of RCCL\n"
+         "  --inject_failure=R:PHASE  tests: rank R fails in phase setup|compute|gather\n"
          "  --synthetic=N,M[,SEED] instead of --input_uri: synthetic cohort of N samples x M "
          "sites generated on the GPU (founders + planted relatives)\n"
          "  --print_schedule       diagnostic: print the multi-GPU schedule (JSON) and "
@@ -170,9 +180,51 @@ std::string ParseFlags(int argc, char **argv, Flags *flags) {
         return "Illegal value '" + value + "' specified for flag 'print_schedule'";
       flags->print_schedule = true;
     } else if (name == "pack") {
-      if (!need_value() || (value != "host" && value != "device"))
+      if (!need_value() || (value != "host" && value != "device" && value != "auto"))
         return "Illegal value '" + value + "' specified for flag 'pack'";
       flags->pack = value;
+    } else if (name == "collectives") {
+      if (!need_value() || (value != "rccl" && value != "loopback"))
+        return "Illegal value '" + value + "' specified for flag 'collectives'";
+      flags->collectives = value;
+    } else if (name == "calibrate") {
+      if (has_value && value != "true" && value != "false" && value != "1" && value != "0")
+        return "Illegal value '" + value + "' specified for flag 'calibrate'";
+      flags->calibrate = !has_value || value == "true" || value == "1";
+    } else if (name == "calibration_tiles") {
+      if (!need_value() || !ParseUnsigned(value, UINT64_MAX, &u))
+        return "Illegal value '" + value + "' specified for flag 'calibration_tiles'";
+      flags->calibration_tiles = u;
+    } else if (name == "rank_weights") {
+      if (!need_value()) return "Missing value for --rank_weights";
+      flags->rank_weights = value;
+      flags->rank_weight_values.clear();
+      size_t pos = 0;
+      while (pos <= value.size()) {
+        const size_t comma = value.find(',', pos);
+        const std::string item =
+            value.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+        errno = 0;
+        char *end = nullptr;
+        const double w = strtod(item.c_str(), &end);
+        if (item.empty() || end == item.c_str() || *end != '\0' || errno != 0 || !(w > 0))
+          return "Illegal value '" + value + "' specified for flag 'rank_weights'";
+        flags->rank_weight_values.push_back(w);
+        if (comma == std::string::npos) break;
+        pos = comma + 1;
+      }
+    } else if (name == "inject_failure") {
+      if (!need_value()) return "Missing value for --inject_failure";
+      const size_t colon = value.find(':');
+      uint64_t r = 0;
+      if (colon == std::string::npos || !ParseUnsigned(value.substr(0, colon), 63, &r))
+        return "Illegal value '" + value + "' specified for flag 'inject_failure'";
+      const std::string phase = value.substr(colon + 1);
+      if (phase != "setup" && phase != "compute" && phase != "gather")
+        return "Illegal value '" + value + "' specified for flag 'inject_failure'";
+      flags->inject_failure = value;
+      flags->inject_failure_rank = (int)r;
+      flags->inject_failure_phase = phase;
     } else {
       return "Unknown command line flag '" + name + "'";
     }

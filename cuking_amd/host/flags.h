@@ -9,6 +9,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <string>
+#include <vector>
 
 namespace cuking_host {
 
@@ -24,7 +25,8 @@ struct Flags {
   // Additions (no reference counterpart).
   int device = 0;                       // HIP device index
   std::string kernel = "tiled";         // tiled | stream
-  std::string pack = "host";            // host | device
+  std::string pack = "auto";            // host | device | auto (device when the
+                                        // reader threads per GPU are few, cuking_main.cc)
   std::string dump_bitset;              // diagnostic: write the packed host
                                         // bitset here and exit (no GPU used)
   // Several GPUs of this node share the shard (multi_gpu.h).  0 = the classic
@@ -33,6 +35,16 @@ struct Flags {
   uint32_t num_gpus = 0;
   std::string multi_gpu_mode = "auto";  // auto | staged | simple
   uint32_t bcast_chunks = 8;
+  // Simple schedule: per-rank weights of the tile ranges ("1,1.05,..."); empty =
+  // measured by a calibration launch per rank (--calibrate, on by default).
+  std::string rank_weights;
+  std::vector<double> rank_weight_values;
+  bool calibrate = true;
+  uint64_t calibration_tiles = 0;       // per rank; 0 = automatic
+  std::string collectives = "rccl";     // rccl | loopback (TEST ONLY: rank threads share one GPU)
+  std::string inject_failure;           // TEST ONLY: "rank:phase" (setup | compute | gather)
+  int inject_failure_rank = -1;
+  std::string inject_failure_phase;
   // "N,M[,seed]": no input tables; the cohort of synth_plan.h is generated on
   // the GPU (BASELINE configs without their 1e9 .. 1.5e11-row Parquet form).
   std::string synthetic;

@@ -1,20 +1,22 @@
 // See multi_gpu.h.  Host code only: HIP runtime API for streams/events/copies,
-// RCCL for the collectives, the C ABI (include/cuking_amd.h) for every kernel.
+// collectives.h (RCCL) for the exchange steps, the C ABI (include/cuking_amd.h)
+// for every kernel.
 #include "multi_gpu.h"
 
 #ifndef __HIP_PLATFORM_AMD__
 #define __HIP_PLATFORM_AMD__ 1
 #endif
 #include <hip/hip_runtime_api.h>
-#include <rccl/rccl.h>
 
 #include <atomic>
 #include <barrier>
 #include <chrono>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <thread>
 
+#include "collectives.h"
 #include "schedule.h"
 
 namespace cuking_host {
@@ -30,13 +32,18 @@ double Now() {
 struct Shared {
   const MultiGpuInput *in;
   MultiGpuOutput *out;
+  Collectives *coll = nullptr;
   bool staged = false;
   uint32_t tile = 0;
   uint64_t num_tiles = 0;
   size_t bit_set_bytes = 0;
-  std::vector<ncclComm_t> comms;
-  std::barrier<> *barrier = nullptr;
   std::atomic<bool> failed{false};
+  // The failure flag as it stood when the LAST rank arrived at the most recent
+  // phase barrier: written by the barrier's completion step, read by every rank
+  // after it -- one value for all of them.  (Reading `failed` itself after the
+  // barrier is a race: a rank that has passed may fail and set it before a
+  // slower peer has looked, and the two then disagree on whether to go on.)
+  bool agreed_failed = false;
   std::mutex mu;
   std::string error, code;
 
@@ -50,6 +57,12 @@ struct Shared {
   }
 };
 
+struct Snapshot {
+  Shared *sh;
+  void operator()() noexcept { sh->agreed_failed = sh->failed.load(); }
+};
+using PhaseBarrier = std::barrier<Snapshot>;
+
 struct RankState {
   int rank = 0, device = 0;
   cuking_ctx *ctx = nullptr;
@@ -58,11 +71,25 @@ struct RankState {
   bool owns_bits = false;
   cuking_result *d_results = nullptr, *d_gather = nullptr;
   uint32_t *d_counters = nullptr, *d_all = nullptr;
+  double *d_rate = nullptr, *d_rates = nullptr;
+  hipEvent_t cal_begin = nullptr, cal_end = nullptr;
   std::vector<hipEvent_t> events;
 
-  ~RankState() {
+  // Nothing of this rank is in flight any more (peers may still be copying out
+  // of its buffers until they have drained theirs: callers pair this with a
+  // barrier where that matters).
+  void Drain() {
     (void)hipSetDevice(device);
+    if (comm) (void)hipStreamSynchronize(comm);
+    if (compute) (void)hipStreamSynchronize(compute);
+    if (copy) (void)hipStreamSynchronize(copy);
+  }
+
+  ~RankState() {
+    Drain();
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    if (cal_begin) (void)hipEventDestroy(cal_begin);
+    if (cal_end) (void)hipEventDestroy(cal_end);
     if (comm) (void)hipStreamDestroy(comm);
     if (compute) (void)hipStreamDestroy(compute);
     if (copy) (void)hipStreamDestroy(copy);
@@ -71,6 +98,8 @@ struct RankState {
     if (d_gather) (void)hipFree(d_gather);
     if (d_counters) (void)hipFree(d_counters);
     if (d_all) (void)hipFree(d_all);
+    if (d_rate) (void)hipFree(d_rate);
+    if (d_rates) (void)hipFree(d_rates);
     if (ctx) cuking_ctx_destroy(ctx);
   }
 };
@@ -97,13 +126,12 @@ struct RankState {
       ok = false;                                                             \
     }                                                                         \
   } while (0)
-#define RANK_NCCL(expr)                                                       \
+// Collectives are issued whatever `ok` says (every rank must make every call).
+#define RANK_COLL(expr)                                                       \
   do {                                                                        \
-    const ncclResult_t r_ = (expr);                                           \
-    if (r_ != ncclSuccess) {                                                  \
-      sh->Fail("INTERNAL", std::string("rank ") + std::to_string(st.rank) +   \
-                               ": " + #expr + " failed: " +                   \
-                               ncclGetErrorString(r_));                       \
+    const std::string m_ = (expr);                                            \
+    if (!m_.empty()) {                                                        \
+      sh->Fail("INTERNAL", std::string("rank ") + std::to_string(st.rank) + ": " + m_); \
       ok = false;                                                             \
     }                                                                         \
   } while (0)
@@ -115,26 +143,49 @@ hipEvent_t NewEvent(RankState &st) {
   return e;
 }
 
+int64_t Option(cuking_ctx *ctx, const char *key) {
+  int64_t v = 0;
+  if (ctx == nullptr || cuking_ctx_get_option(ctx, key, &v) != CUKING_OK) return 0;
+  return v;
+}
+
 // The whole job of one rank.  Every collective is issued by every rank in the
 // same order whatever happens locally: a rank whose own work failed keeps
 // taking part (with nothing to contribute) and the failure is agreed on at the
-// host barriers, so nobody is left waiting inside RCCL for a rank that gave up.
-void RankMain(Shared *sh, int rank) {
+// phase barriers (Shared::agreed_failed), so nobody is left waiting inside RCCL
+// or at a barrier for a rank that gave up.
+void RankMain(Shared *sh, PhaseBarrier *barrier, int rank) {
   const MultiGpuInput &in = *sh->in;
   const int world = in.num_gpus;
+  Collectives *coll = sh->coll;
   RankState st;
   st.rank = rank;
-  st.device = in.first_device + rank;
+  st.device = in.collectives == "loopback" ? in.first_device : in.first_device + rank;
   bool ok = true;
   const uint32_t wps = in.words_per_sample;
   const uint32_t stored = cuking_submatrix_num_samples(&in.sm);
+  const bool tiled = in.kernel != "stream";
+  auto inject = [&](const char *phase) {
+    if (rank == in.inject_failure_rank && in.inject_failure_phase == phase) {
+      sh->Fail("INTERNAL", std::string("rank ") + std::to_string(rank) +
+                               ": injected failure in phase " + phase);
+      ok = false;
+    }
+  };
+  // Agreement at the end of a phase: true = somebody failed, everybody stops.
+  auto phase_failed = [&]() {
+    barrier->arrive_and_wait();
+    if (!sh->agreed_failed) return false;
+    st.Drain();
+    barrier->arrive_and_wait();  // ... and nobody frees what a peer still reads
+    return true;
+  };
 
   // ---- setup ----------------------------------------------------------------
   RANK_HIP(hipSetDevice(st.device));
   if (ok) RANK_ABI(cuking_ctx_create(st.device, &st.ctx));
   if (ok)
-    RANK_ABI(cuking_ctx_set_kernel(st.ctx, in.kernel == "stream" ? CUKING_KERNEL_STREAM
-                                                                 : CUKING_KERNEL_TILED));
+    RANK_ABI(cuking_ctx_set_kernel(st.ctx, tiled ? CUKING_KERNEL_TILED : CUKING_KERNEL_STREAM));
   if (ok) RANK_ABI(cuking_timing_enable(st.ctx, 1));
   if (ok) RANK_HIP(hipStreamCreateWithFlags(&st.comm, hipStreamNonBlocking));
   if (ok) RANK_HIP(hipStreamCreateWithFlags(&st.compute, hipStreamNonBlocking));
@@ -150,11 +201,28 @@ void RankMain(Shared *sh, int rank) {
   }
   const size_t result_bytes = (size_t)(in.max_results ? in.max_results : 1) * sizeof(cuking_result);
   if (ok) RANK_HIP(hipMalloc(reinterpret_cast<void **>(&st.d_results), result_bytes));
+  // (the total over the ranks is held to max_results, so this is all rank 0 can receive)
+  if (ok && rank == 0 && world > 1)
+    RANK_HIP(hipMalloc(reinterpret_cast<void **>(&st.d_gather), result_bytes));
   if (ok) RANK_HIP(hipMalloc(reinterpret_cast<void **>(&st.d_counters), 2 * sizeof(uint32_t)));
   if (ok) RANK_HIP(hipMalloc(reinterpret_cast<void **>(&st.d_all), 2 * sizeof(uint32_t) * world));
+  if (ok) RANK_HIP(hipMalloc(reinterpret_cast<void **>(&st.d_rate), sizeof(double)));
+  if (ok) RANK_HIP(hipMalloc(reinterpret_cast<void **>(&st.d_rates), sizeof(double) * world));
+  if (ok) RANK_HIP(hipEventCreate(&st.cal_begin));
+  if (ok) RANK_HIP(hipEventCreate(&st.cal_end));
   if (ok) RANK_HIP(hipMemsetAsync(st.d_counters, 0, 2 * sizeof(uint32_t), st.compute));
-  sh->barrier->arrive_and_wait();
-  if (sh->failed.load()) return;  // nobody has issued a collective yet
+  // The kernel layout of the whole block, the tile prefix and the compute
+  // stream's split slab, NOW: once the first broadcast is enqueued no rank may
+  // allocate or wait for its device (a blocking allocation beside in-flight
+  // RCCL kernels of the other devices of this process can deadlock them).
+  if (ok && tiled) {
+    void *streams[1] = {st.compute};
+    RANK_ABI(cuking_ctx_reserve(st.ctx, &in.sm, wps, streams, 1));
+  }
+  const int64_t allocs_reserved = Option(st.ctx, "workspace_allocations");
+  const int64_t syncs_reserved = Option(st.ctx, "host_syncs");
+  inject("setup");
+  if (phase_failed()) return;  // nobody has issued a collective yet
 
   // ---- exchange step 1 + compute ---------------------------------------------
   const double t0 = Now();
@@ -172,9 +240,7 @@ void RankMain(Shared *sh, int rank) {
       if (ok && up) RANK_HIP(hipEventRecord(up, st.copy));
       if (ok && up) RANK_HIP(hipStreamWaitEvent(st.comm, up, 0));
     }
-    // (with one rank this is RCCL's single-rank broadcast: the same calls run)
-    RANK_NCCL(ncclBroadcast(st.d_bits + off, st.d_bits + off, bytes, ncclUint8, 0,
-                            sh->comms[rank], st.comm));
+    RANK_COLL(coll->Broadcast(rank, st.d_bits + off, bytes, 0, st.comm));
     hipEvent_t arrived = NewEvent(st);
     if (ok && arrived) RANK_HIP(hipEventRecord(arrived, st.comm));
     if (ok && arrived) RANK_HIP(hipStreamWaitEvent(st.compute, arrived, 0));
@@ -190,31 +256,73 @@ void RankMain(Shared *sh, int rank) {
             st.d_counters, st.d_counters + 1, st.compute));
     }
   }
-  if (!sh->staged && ok) {
-    if (in.kernel == "stream") {
+  TileRange mine = {0, 0};
+  std::vector<double> rates;
+  uint64_t cal_tiles = 0;
+  if (!sh->staged) {
+    auto launch_tiles = [&](uint64_t begin, uint64_t end) {
+      if (ok && end > begin)
+        RANK_ABI(cuking_compute_king_tiles(st.ctx, &in.sm, wps, st.d_bits, begin, end,
+                                           in.kin_threshold, in.max_results, st.d_results,
+                                           st.d_counters, st.d_counters + 1, st.compute));
+    };
+    if (!tiled) {
       // the streaming kernel has no tile enumeration: rank 0 takes the block
-      if (rank == 0)
+      if (rank == 0 && ok)
         RANK_ABI(cuking_compute_king(st.ctx, &in.sm, wps, st.d_bits, in.kin_threshold,
                                      in.max_results, st.d_results, st.d_counters,
                                      st.d_counters + 1, st.compute));
+    } else if (!in.rank_weights.empty()) {
+      mine = WeightedTilePartition(sh->num_tiles, in.rank_weights)[rank];
+      launch_tiles(mine.begin, mine.end);
+    } else if (in.calibrate && world > 1 &&
+               (cal_tiles = in.calibration_tiles != 0 &&
+                                    in.calibration_tiles * (uint64_t)world <= sh->num_tiles
+                                ? in.calibration_tiles
+                                : CalibrationTiles(sh->num_tiles, world)) != 0) {
+      // The GPUs of a node run this kernel several percent apart: every rank
+      // times a small range of its own, the rates are exchanged, and the rest
+      // of the enumeration is cut in proportion (schedule.h).  Same decision
+      // and same collective on every rank.
+      if (ok) RANK_HIP(hipEventRecord(st.cal_begin, st.compute));
+      launch_tiles((uint64_t)rank * cal_tiles, (uint64_t)(rank + 1) * cal_tiles);
+      if (ok) RANK_HIP(hipEventRecord(st.cal_end, st.compute));
+      double rate = 0;  // a rank that failed contributes 0: equal ranges then
+      float ms = 0;
+      if (ok) RANK_HIP(hipEventSynchronize(st.cal_end));
+      if (ok) RANK_HIP(hipEventElapsedTime(&ms, st.cal_begin, st.cal_end));
+      if (ok && ms > 0) rate = (double)cal_tiles / ms;
+      if (ok) RANK_HIP(hipMemcpyAsync(st.d_rate, &rate, sizeof(double), hipMemcpyHostToDevice,
+                                      st.compute));
+      RANK_COLL(coll->AllGather(rank, st.d_rate, st.d_rates, sizeof(double), st.compute));
+      rates.assign(world, 0.0);
+      if (ok) RANK_HIP(hipMemcpyAsync(rates.data(), st.d_rates, sizeof(double) * world,
+                                      hipMemcpyDeviceToHost, st.compute));
+      if (ok) RANK_HIP(hipStreamSynchronize(st.compute));
+      bool usable = ok;
+      for (double r : rates) usable = usable && std::isfinite(r) && r > 0;
+      const uint64_t done = (uint64_t)world * cal_tiles, rest = sh->num_tiles - done;
+      // (a rank that cannot use the rates has failed: what it launches no longer matters)
+      mine = usable ? WeightedTilePartition(rest, rates)[rank] : TilePartition(rest, world)[rank];
+      mine.begin += done;
+      mine.end += done;
+      launch_tiles(mine.begin, mine.end);
     } else {
-      const TileRange mine = TilePartition(sh->num_tiles, world)[rank];
-      RANK_ABI(cuking_compute_king_tiles(st.ctx, &in.sm, wps, st.d_bits, mine.begin, mine.end,
-                                         in.kin_threshold, in.max_results, st.d_results,
-                                         st.d_counters, st.d_counters + 1, st.compute));
+      mine = TilePartition(sh->num_tiles, world)[rank];
+      launch_tiles(mine.begin, mine.end);
     }
   }
+  inject("compute");
 
   // ---- exchange step 2: counts, then records ---------------------------------
-  RANK_NCCL(ncclAllGather(st.d_counters, st.d_all, 2, ncclUint32, sh->comms[rank], st.compute));
+  RANK_COLL(coll->AllGather(rank, st.d_counters, st.d_all, 2 * sizeof(uint32_t), st.compute));
   std::vector<uint32_t> all(2 * (size_t)world, 0);
   if (ok) RANK_HIP(hipMemcpyAsync(all.data(), st.d_all, all.size() * sizeof(uint32_t),
                                   hipMemcpyDeviceToHost, st.compute));
   if (ok) RANK_HIP(hipStreamSynchronize(st.compute));   // kernel errors surface here
   if (ok) RANK_HIP(hipStreamSynchronize(st.comm));
   const double t1 = Now();
-  sh->barrier->arrive_and_wait();
-  if (sh->failed.load()) return;  // every rank has finished its collectives so far
+  if (phase_failed()) return;  // every rank has finished its collectives so far
 
   std::vector<uint32_t> counts(world);
   bool overflow = false;
@@ -231,24 +339,15 @@ void RankMain(Shared *sh, int rank) {
                "Could not store all results: try increasing the --max_results parameter.");
     return;  // same decision on every rank (same data): no collective is left half-issued
   }
-  if (rank == 0 && world > 1)
-    RANK_HIP(hipMalloc(reinterpret_cast<void **>(&st.d_gather),
-                       (size_t)(plan.total ? plan.total : 1) * sizeof(cuking_result)));
-  // (an allocation failure on rank 0 is agreed on before anybody sends)
-  sh->barrier->arrive_and_wait();
-  if (sh->failed.load()) return;
-  if (world > 1) {
-    RANK_NCCL(ncclGroupStart());
-    if (rank == 0) {
-      for (int r = 1; r < world; ++r)
-        if (counts[r])
-          RANK_NCCL(ncclRecv(st.d_gather + plan.offset[r], (size_t)counts[r] * 6, ncclUint32, r,
-                             sh->comms[rank], st.compute));
-    } else if (counts[rank]) {
-      RANK_NCCL(ncclSend(st.d_results, (size_t)counts[rank] * 6, ncclUint32, 0,
-                         sh->comms[rank], st.compute));
+  inject("gather");
+  if (phase_failed()) return;  // (a failure here is agreed on before anybody sends)
+  {
+    std::vector<uint64_t> bytes(world), offset(world);
+    for (int r = 0; r < world; ++r) {
+      bytes[r] = (uint64_t)counts[r] * sizeof(cuking_result);
+      offset[r] = plan.offset[r] * sizeof(cuking_result);
     }
-    RANK_NCCL(ncclGroupEnd());
+    RANK_COLL(coll->GatherToRoot(rank, st.d_results, st.d_gather, bytes, offset, st.compute));
   }
   if (rank == 0) {
     sh->out->results.resize(plan.total);
@@ -272,12 +371,19 @@ void RankMain(Shared *sh, int rank) {
     sh->out->rank_kernel_ms[rank] = king_ms;
     sh->out->rank_prepare_ms[rank] = prep_ms;
     sh->out->rank_results[rank] = counts[rank];
+    sh->out->rank_allocations_after_reserve[rank] =
+        (uint64_t)(Option(st.ctx, "workspace_allocations") - allocs_reserved);
+    sh->out->rank_host_syncs_after_reserve[rank] =
+        (uint64_t)(Option(st.ctx, "host_syncs") - syncs_reserved);
+    if (!sh->staged && tiled) sh->out->rank_tile_ranges[rank] = {mine.begin, mine.end};
     if (rank == 0) {
       sh->out->exchange_and_compute_seconds = t1 - t0;
       sh->out->gather_seconds = t2 - t1;
+      sh->out->rank_rates = rates;
+      sh->out->calibration_tiles = cal_tiles;
     }
   }
-  sh->barrier->arrive_and_wait();  // nobody tears down while a peer still receives
+  barrier->arrive_and_wait();  // nobody tears down while a peer still receives
 }
 
 }  // namespace
@@ -290,14 +396,25 @@ std::string RunMultiGpu(const MultiGpuInput &in, MultiGpuOutput *out, std::strin
     *code = c;
     return m;
   };
+  const bool loopback = in.collectives == "loopback";
+  if (!loopback && in.collectives != "rccl")
+    return fail("INVALID_ARGUMENT", "unknown collectives implementation " + in.collectives);
   const int available = cuking_device_count();
   if (available <= 0)
     return fail("INTERNAL", "no HIP device available; this program has no CPU path");
-  if (in.num_gpus < 1 || in.first_device < 0 || in.first_device + in.num_gpus > available)
+  if (in.num_gpus < 1 || in.first_device < 0 ||
+      in.first_device + (loopback ? 1 : in.num_gpus) > available)
     return fail("INVALID_ARGUMENT",
                 "--num_gpus=" + std::to_string(in.num_gpus) + " from device " +
                     std::to_string(in.first_device) + ", but " + std::to_string(available) +
                     " GPU(s) are visible");
+  if (!in.rank_weights.empty()) {
+    if ((int)in.rank_weights.size() != in.num_gpus)
+      return fail("INVALID_ARGUMENT", "--rank_weights needs one weight per GPU");
+    for (double w : in.rank_weights)
+      if (!(w > 0) || !std::isfinite(w))
+        return fail("INVALID_ARGUMENT", "--rank_weights must be positive");
+  }
   const bool diag = in.sm.i_begin == in.sm.j_begin;
   if (in.mode == "staged" && (!diag || in.kernel == "stream"))
     return fail("INVALID_ARGUMENT",
@@ -311,25 +428,27 @@ std::string RunMultiGpu(const MultiGpuInput &in, MultiGpuOutput *out, std::strin
   out->rank_kernel_ms.assign(in.num_gpus, 0);
   out->rank_prepare_ms.assign(in.num_gpus, 0);
   out->rank_results.assign(in.num_gpus, 0);
+  out->rank_allocations_after_reserve.assign(in.num_gpus, 0);
+  out->rank_host_syncs_after_reserve.assign(in.num_gpus, 0);
+  out->rank_tile_ranges.assign(in.num_gpus, {0, 0});
 
   std::vector<int> devices(in.num_gpus);
-  for (int r = 0; r < in.num_gpus; ++r) devices[r] = in.first_device + r;
-  sh.comms.assign(in.num_gpus, nullptr);
+  for (int r = 0; r < in.num_gpus; ++r) devices[r] = loopback ? in.first_device : in.first_device + r;
+  std::unique_ptr<Collectives> coll = loopback ? MakeLoopbackCollectives() : MakeRcclCollectives();
+  sh.coll = coll.get();
+  out->collectives = coll->name();
   const auto init_t0 = std::chrono::steady_clock::now();
-  const ncclResult_t rc = ncclCommInitAll(sh.comms.data(), in.num_gpus, devices.data());
+  const std::string init_error = coll->InitAll(devices);
   out->comm_init_seconds =
       std::chrono::duration<double>(std::chrono::steady_clock::now() - init_t0).count();
-  if (rc != ncclSuccess)
-    return fail("INTERNAL", std::string("ncclCommInitAll failed: ") + ncclGetErrorString(rc));
+  if (!init_error.empty()) return fail("INTERNAL", init_error);
 
-  std::barrier<> barrier(in.num_gpus);
-  sh.barrier = &barrier;
+  PhaseBarrier barrier(in.num_gpus, Snapshot{&sh});
   std::vector<std::thread> threads;
-  for (int r = 1; r < in.num_gpus; ++r) threads.emplace_back(RankMain, &sh, r);
-  RankMain(&sh, 0);
+  for (int r = 1; r < in.num_gpus; ++r) threads.emplace_back(RankMain, &sh, &barrier, r);
+  RankMain(&sh, &barrier, 0);
   for (auto &t : threads) t.join();
-  for (ncclComm_t c : sh.comms)
-    if (c) (void)ncclCommDestroy(c);
+  coll->Destroy();
   if (sh.failed.load()) {
     *code = sh.code;
     return sh.error;

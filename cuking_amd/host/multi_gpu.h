@@ -1,7 +1,7 @@
 // One block over N GPUs of this node from ONE process: a host thread, a
-// context and two streams per GPU, RCCL (ncclCommInitAll) for the two exchange
-// steps -- chunked broadcast of the packed bitset from the GPU that holds it,
-// gather of the thresholded records on rank 0.  north_star: "block-partitioned
+// context and three streams per GPU, RCCL (behind collectives.h) for the two
+// exchange steps -- chunked broadcast of the packed bitset from the GPU that
+// holds it, gather of the thresholded records on rank 0.  north_star: "block-partitioned
 // across the 8 GPUs of one node, bitset halves broadcast with RCCL over xGMI,
 // thresholded pair lists gathered at the end"; reference anchor: Run() is C++
 // end to end (cuking.cu:435-882) and fans shards out over VMs instead
@@ -31,6 +31,19 @@ struct MultiGpuInput {
   uint64_t *d_bits_rank0 = nullptr;
   float kin_threshold = 0.f;
   uint32_t max_results = 0;
+  // "rccl" (product) or "loopback" (TEST ONLY, collectives.h: rank threads may
+  // then share a GPU -- every rank runs on first_device).
+  std::string collectives = "rccl";
+  // Simple schedule: tile ranges in proportion to these per-rank weights; empty
+  // = measure them (one calibration launch per rank, schedule.h) unless
+  // `calibrate` is off or the job is small, then equal ranges.
+  std::vector<double> rank_weights;
+  bool calibrate = true;
+  uint64_t calibration_tiles = 0;  // per rank; 0 = schedule.h CalibrationTiles()
+  // TEST ONLY: rank `inject_failure_rank` reports a failure in phase "setup",
+  // "compute" or "gather" (exercises the agreement on failures).
+  int inject_failure_rank = -1;
+  std::string inject_failure_phase;
 };
 
 struct MultiGpuOutput {
@@ -41,6 +54,15 @@ struct MultiGpuOutput {
   std::vector<double> rank_kernel_ms, rank_prepare_ms;
   std::vector<uint32_t> rank_results;
   uint64_t bytes_broadcast = 0;
+  std::string collectives;             // implementation that ran
+  // Simple schedule: the tile range each rank evaluated after calibration and
+  // the rates (tiles / ms) behind the cut (empty: equal ranges).
+  std::vector<std::pair<uint64_t, uint64_t>> rank_tile_ranges;
+  std::vector<double> rank_rates;
+  uint64_t calibration_tiles = 0;      // per rank
+  // Workspace allocations / host-side waits the library made on a rank AFTER
+  // cuking_ctx_reserve, i.e. while collectives may be in flight: must be 0.
+  std::vector<uint64_t> rank_allocations_after_reserve, rank_host_syncs_after_reserve;
 };
 
 // Returns "" on success; otherwise the message, with *code set to the

@@ -58,37 +58,75 @@ std::string ReadColumn(parquet::ColumnReader *column, int64_t rows,
 
 }  // namespace
 
-std::string ReadTriples(const std::string &path, Triples *out) {
+namespace {
+
+// cuking.cu:585-590, :608-613, :630-635, :652-657: three columns by position,
+// INT64 / INT64 / INT32.
+std::string CheckSchema(const parquet::FileMetaData &meta, const std::string &path) {
+  constexpr int kNumColumns = 3;
+  if (meta.num_columns() != kNumColumns) {
+    std::ostringstream os;
+    os << "Expected " << kNumColumns << " columns, found " << meta.num_columns() << " in "
+       << path;
+    return os.str();
+  }
+  const parquet::Type::type want[kNumColumns] = {parquet::Type::INT64, parquet::Type::INT64,
+                                                 parquet::Type::INT32};
+  for (int c = 0; c < kNumColumns; ++c) {
+    const auto got = meta.schema()->Column(c)->physical_type();
+    if (got != want[c]) {
+      std::ostringstream os;
+      os << "Expected " << parquet::TypeToString(want[c]) << " type, found "
+         << parquet::TypeToString(got) << " in " << path;
+      return os.str();
+    }
+  }
+  return "";
+}
+
+}  // namespace
+
+std::string CountRowGroups(const std::string &path, int *num_row_groups) {
   try {
     std::unique_ptr<parquet::ParquetFileReader> file =
         parquet::ParquetFileReader::OpenFile(path, /*memory_map=*/false);
     const auto meta = file->metadata();
-    constexpr int kNumColumns = 3;  // cuking.cu:585-590
-    if (meta->num_columns() != kNumColumns) {
+    const std::string err = CheckSchema(*meta, path);
+    if (!err.empty()) return err;
+    *num_row_groups = meta->num_row_groups();
+    return "";
+  } catch (const std::exception &e) {  // cuking.cu:580-583
+    return std::string("Error reading ") + path + ": " + e.what();
+  }
+}
+
+std::string ReadTriples(const std::string &path, int row_group, Triples *out) {
+  try {
+    std::unique_ptr<parquet::ParquetFileReader> file =
+        parquet::ParquetFileReader::OpenFile(path, /*memory_map=*/false);
+    const auto meta = file->metadata();
+    {
+      const std::string err = CheckSchema(*meta, path);
+      if (!err.empty()) return err;
+    }
+    if (row_group >= meta->num_row_groups()) {
       std::ostringstream os;
-      os << "Expected " << kNumColumns << " columns, found "
-         << meta->num_columns() << " in " << path;
+      os << "row group " << row_group << " outside the " << meta->num_row_groups() << " of "
+         << path;
       return os.str();
     }
-    const parquet::Type::type want[kNumColumns] = {
-        parquet::Type::INT64, parquet::Type::INT64, parquet::Type::INT32};
-    for (int c = 0; c < kNumColumns; ++c) {
-      const auto got = meta->schema()->Column(c)->physical_type();
-      if (got != want[c]) {  // cuking.cu:608-613, :630-635, :652-657
-        std::ostringstream os;
-        os << "Expected " << parquet::TypeToString(want[c]) << " type, found "
-           << parquet::TypeToString(got) << " in " << path;
-        return os.str();
-      }
-    }
+    const int g_begin = row_group < 0 ? 0 : row_group;
+    const int g_end = row_group < 0 ? meta->num_row_groups() : row_group + 1;
+    int64_t expect = 0;
+    for (int g = g_begin; g < g_end; ++g) expect += meta->RowGroup(g)->num_rows();
     out->row_idx.clear();
     out->col_idx.clear();
     out->n_alt_alleles.clear();
-    out->row_idx.reserve((size_t)meta->num_rows());
-    out->col_idx.reserve((size_t)meta->num_rows());
-    out->n_alt_alleles.reserve((size_t)meta->num_rows());
+    out->row_idx.reserve((size_t)expect);
+    out->col_idx.reserve((size_t)expect);
+    out->n_alt_alleles.reserve((size_t)expect);
     std::vector<uint8_t> alt_valid;
-    for (int g = 0; g < meta->num_row_groups(); ++g) {
+    for (int g = g_begin; g < g_end; ++g) {
       auto group = file->RowGroup(g);
       const int64_t rows = group->metadata()->num_rows();
       std::string err;

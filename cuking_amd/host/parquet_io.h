@@ -20,10 +20,16 @@ struct Triples {
   std::vector<int32_t> n_alt_alleles;
 };
 
-// Reads one input table.  Spark writes OPTIONAL columns: those are accepted;
-// a null row_idx / col_idx is an error, a null n_alt_alleles drops the entry
-// (= missing genotype).  Returns "" or the error message.
-std::string ReadTriples(const std::string &path, Triples *out);
+// Reads one input table -- all of it (row_group < 0), or one of its row groups,
+// so that the unit of parallelism of the decode is the row group, not the file
+// (the reference parallelises over files only, cuking.cu:550-553).  Spark writes
+// OPTIONAL columns: those are accepted; a null row_idx / col_idx is an error, a
+// null n_alt_alleles drops the entry (= missing genotype).  Returns "" or the
+// error message.
+std::string ReadTriples(const std::string &path, int row_group, Triples *out);
+// Number of row groups of a table (reads the footer only; validates the schema
+// like ReadTriples).
+std::string CountRowGroups(const std::string &path, int *num_row_groups);
 
 // Writes `results[0..n)` (already sorted) with sample ids looked up by index.
 std::string WriteResults(const std::string &path, const cuking_result *results,

@@ -16,6 +16,7 @@
 #ifndef CUKING_AMD_HOST_SCHEDULE_H_
 #define CUKING_AMD_HOST_SCHEDULE_H_
 
+#include <cmath>
 #include <cstdint>
 #include <vector>
 
@@ -36,6 +37,48 @@ inline std::vector<TileRange> TilePartition(uint64_t num_tiles, uint32_t world) 
     begin = end;
   }
   return out;
+}
+
+// Contiguous ranges proportional to `weights` (a rank's measured speed, tiles
+// per millisecond): the GPUs of one node sustain clocks several percent apart
+// under this kernel, and with equal ranges the slowest one sets the pace.
+// Exact cover of [0, num_tiles), monotone.  Same arithmetic as
+// cuking_amd/dist.py weighted_tile_partition (round half to even).
+inline std::vector<TileRange> WeightedTilePartition(uint64_t num_tiles,
+                                                    const std::vector<double> &weights) {
+  std::vector<TileRange> out;
+  double total = 0;
+  for (double w : weights) total += w;
+  uint64_t begin = 0;
+  double acc = 0;
+  for (size_t r = 0; r < weights.size(); ++r) {
+    acc += weights[r];
+    uint64_t end = num_tiles;
+    if (r + 1 != weights.size()) {
+      const double cut = std::nearbyint((double)num_tiles * acc / total);
+      end = cut <= (double)begin ? begin : (uint64_t)cut;
+      if (end > num_tiles) end = num_tiles;
+    }
+    out.push_back({begin, end});
+    begin = end;
+  }
+  return out;
+}
+
+// Calibration of the simple schedule: every rank first evaluates
+// CalibrationTiles() tiles of its own (rank r: [r * c, (r + 1) * c)), timed
+// with events; the rates are all-gathered and the remaining tiles
+// [world * c, num_tiles) are cut in proportion (WeightedTilePartition).  About
+// 2 % of a rank's share, whole rounds of 256 workgroups, at least 8 rounds --
+// and none (0) for jobs under 64 rounds per rank, where a few percent of
+// imbalance cost less than the extra launch and the rate exchange.
+inline uint64_t CalibrationTiles(uint64_t num_tiles, uint32_t world) {
+  if (world < 2) return 0;
+  const uint64_t share = num_tiles / world;
+  if (share < 64 * 256) return 0;
+  uint64_t c = share / 50 / 256 * 256;
+  if (c < 8 * 256) c = 8 * 256;
+  return c;
 }
 
 struct SampleChunk {

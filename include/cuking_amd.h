@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CUKING_ABI_VERSION 1
+#define CUKING_ABI_VERSION 2
 
 typedef enum cuking_status {
   CUKING_OK = 0,
@@ -201,7 +201,8 @@ cuking_status cuking_ctx_set_kernel(cuking_ctx *ctx, cuking_kernel kernel);
 cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
                                     int64_t value);
 /* Current value of "variant", "split_wgs", "band_rows", "xcd_swizzle",
- * "dyn_tail_tiles" or "counts_mode". */
+ * "dyn_tail_tiles", "counts_mode" or "reuse_prepared"; read-only counters
+ * "workspace_allocations", "host_syncs", "conversions_skipped". */
 cuking_status cuking_ctx_get_option(const cuking_ctx *ctx, const char *key,
                                     int64_t *value);
 int cuking_num_variants(void);
@@ -291,6 +292,30 @@ cuking_status cuking_compute_king_rect(
     uint32_t row_step, uint32_t col_begin, uint32_t col_end, float kin_threshold,
     uint32_t max_results, cuking_result *d_results, uint32_t *d_result_index,
     uint32_t *d_result_overflow, void *stream);
+
+/* Sizes the context's workspace for `sm` up front: the kernel-internal layout
+ * of the block (cuking.cu:513-523 sizes the reference's one buffer the same
+ * way, before anything runs), the tile enumeration's prefix table and, for each
+ * of the `num_streams` (<= 8) streams named, the remainder-split slab of the
+ * matrix-core kernel.  Afterwards the compute / prepare calls for this block
+ * (or a smaller one) on those streams allocate nothing and never wait for the
+ * device -- which a host that drives several GPUs from one process needs once
+ * collectives are in flight (host/multi_gpu.cc reserves before its first
+ * broadcast).  May synchronise the device itself.  The context's
+ * "workspace_allocations" / "host_syncs" options (cuking_ctx_get_option) count
+ * the allocations and host-side waits made on behalf of the workspace so far. */
+cuking_status cuking_ctx_reserve(cuking_ctx *ctx, const cuking_submatrix *sm,
+                                 uint32_t words_per_sample, void *const *streams,
+                                 size_t num_streams);
+
+/* With the option "reuse_prepared" = 1 a compute / prepare call whose block,
+ * width, kernel shape and bitset POINTER equal those of the layout the
+ * workspace already holds launches the pair kernel only (the conversion is
+ * 1.7 % of a 10k x 100k-site call).  The host thereby promises not to rewrite
+ * that bitset in place without calling cuking_invalidate() before the next
+ * compute call.  Default 0: like ComputeKingKernel (cuking.cu:191-195), every
+ * call reads whatever the bitset holds when it runs. */
+cuking_status cuking_invalidate(cuking_ctx *ctx);
 
 /* Diagnostic: the six sums of every pair, no threshold.  d_counts holds
  * NumRows x NumCols records, pair (i, j) at [(i - i_begin) * NumCols +

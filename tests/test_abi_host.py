@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in the header, not exported"
     # and the binding table covers exactly the header
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.cuking_abi_version() == 1
+    assert lib.cuking_abi_version() == 2
 
 
 def test_header_is_plain_c(tmp_path):

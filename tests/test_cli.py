@@ -174,6 +174,86 @@ def test_multi_gpu_schedule_matches_python_driver(tmp_path, n, k, shard, world, 
                 assert tuple(step["rows"]) == rect[0] and rect[1] == (c0, c1)
 
 
+def test_weighted_tile_ranges_and_calibration_plan(tmp_path):
+    """`--rank_weights` / calibration of the simple schedule (host/schedule.h)
+    against cuking_amd.dist.weighted_tile_partition, and the new flags' errors."""
+    from cuking_amd.dist import weighted_tile_partition
+    d = tmp_path / "in"
+    d.mkdir()
+    n = 300_000
+    (d / "metadata.json").write_text(json.dumps(
+        {"num_sites": 64, "samples": [f"s{i}" for i in range(n)]}))
+
+    def schedule(*extra):
+        p = run_cli("--input_uri", d, "--output_uri", tmp_path / "o", "--print_schedule",
+                    "--num_gpus=8", "--multi_gpu_mode=simple", *extra, check=True)
+        return json.loads(p.stdout.strip().splitlines()[-1])
+
+    weights = [1.0, 1.03, 0.97, 1.01, 1.0, 0.95, 1.06, 1.0]
+    got = schedule("--rank_weights=" + ",".join(map(str, weights)))
+    assert got["weighted"] is True and got["calibration_tiles"] == 0
+    want = weighted_tile_partition(got["num_tiles"], weights)
+    assert [tuple(r) for r in got["tile_ranges"]] == want
+    sizes = [b - a for a, b in want]
+    assert sizes[6] > sizes[0] > sizes[5] and sum(sizes) == got["num_tiles"]
+    # no weights: equal ranges as the fall-back, and a calibration launch of about
+    # 2 % of a rank's share (whole rounds of 256 workgroups)
+    got = schedule()
+    share = got["num_tiles"] // 8
+    assert got["weighted"] is False
+    assert got["calibration_tiles"] % 256 == 0
+    assert 0.015 * share <= got["calibration_tiles"] <= 0.021 * share
+    assert schedule("--calibrate=false")["calibration_tiles"] == 0
+    assert schedule("--calibration_tiles=512")["calibration_tiles"] == 512
+    # small jobs do not calibrate
+    (d / "metadata.json").write_text(json.dumps(
+        {"num_sites": 64, "samples": [f"s{i}" for i in range(5000)]}))
+    assert schedule()["calibration_tiles"] == 0
+    for bad, needle in (("--rank_weights=1,0", "rank_weights"), ("--rank_weights=a", "rank_weights"),
+                        ("--collectives=mpi", "collectives"), ("--inject_failure=1", "inject_failure"),
+                        ("--inject_failure=1:later", "inject_failure"), ("--pack=gpu", "pack"),
+                        ("--calibrate=maybe", "calibrate")):
+        p = run_cli("--input_uri", d, "--output_uri", tmp_path / "o", bad)
+        assert p.returncode == 1 and needle in p.stderr, (bad, p.stderr)
+
+
+def test_host_threads_under_tsan(tmp_path, oracle):
+    """ThreadSanitizer over the threaded host code: the reader pool (ParallelFor,
+    one task per row group) decoding on 8 threads while cuking_pack_host's relaxed
+    atomic ANDs (cuking.cu:317-323, :550-553) land in ONE shared bitset.  The
+    host-only half of the ABI (csrc/king_host.cc, plain C++) is compiled INTO the
+    instrumented binary, in front of the copy inside libcuking_amd.so, so the
+    pack itself is instrumented.  CPU only (--dump_bitset touches no GPU)."""
+    from cuking_amd import build as b
+    inc, libdir, libs = b.arrow_flags()
+    exe = tmp_path / "cuking_tsan"
+    cmd = ["g++", "-O1", "-g", "-std=c++20", "-fsanitize=thread", "-pthread", f"-I{b.INCLUDE}",
+           f"-I{b.HOST}", f"-I{b.CSRC}", f"-isystem{inc}", *b.ROCM_HOST_FLAGS,
+           *map(str, sorted(b.HOST.glob("*.cc"))),
+           *[str(b.CSRC / f) for f in b.HOST_ABI_SOURCES],
+           "-o", str(exe), f"-L{b.PKG}", "-l:libcuking_amd.so", f"-L{libdir}", *libs,
+           *b.ROCM_HOST_LIBS,
+           f"-Wl,-rpath,{libdir}", f"-Wl,-rpath,{b.PKG}", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True)
+    rng = np.random.default_rng(12)
+    geno = random_genotypes(rng, 61, 900, missing=0.1)
+    write_input_tables(tmp_path / "in", geno, num_files=2, row_group_size=4000,
+                       spark_layout=False)
+    dump = tmp_path / "bits.bin"
+    supp = Path(__file__).parent / "tsan.supp"      # prebuilt libarrow / libparquet only
+    env = dict(**__import__("os").environ,
+               TSAN_OPTIONS=f"halt_on_error=1 exitcode=66 suppressions={supp}")
+    p = subprocess.run([str(exe), "--input_uri", str(tmp_path / "in"), "--output_uri",
+                        str(tmp_path / "o"), "--dump_bitset", str(dump),
+                        "--num_reader_threads=8"], capture_output=True, text=True, env=env,
+                       timeout=600)
+    assert p.returncode == 0 and "ThreadSanitizer" not in p.stderr, p.stderr[-4000:]
+    tasks = int(p.stdout.split(" decode tasks")[0].split()[-1])
+    assert tasks > 8                                   # row groups, not files, were the unit
+    got = np.fromfile(dump, dtype=np.uint64).reshape(61, -1)
+    assert np.array_equal(got, oracle.bitset_from_genotypes(geno))
+
+
 # ------------------------------------------------- decode + pack (CPU) ----
 def dump_bits(in_dir, tmp_path, n_stored, wps, *extra):
     dump = tmp_path / "bits.bin"
@@ -207,6 +287,31 @@ def test_parquet_decode_and_pack_match_oracle(tmp_path, oracle, layout):
                         (0 if osm.i_begin == osm.j_begin else osm.j_end - osm.j_begin),
                         wps, f"--split_factor={k}", f"--shard_index={shard}")
         assert np.array_equal(got, oracle.bitset_from_genotypes(geno, osm))
+
+
+def test_row_groups_are_the_unit_of_the_decode(tmp_path, oracle):
+    """Fewer files than reader threads: one decode task per (file, row group)
+    (the reference hands out whole files, cuking.cu:550-553); same bitset."""
+    import pyarrow.parquet as pq
+    rng = np.random.default_rng(23)
+    n, m = 41, 1200
+    geno = random_genotypes(rng, n, m, missing=0.1)
+    in_dir = tmp_path / "in"
+    paths = write_input_tables(in_dir, geno, num_files=2, row_group_size=5000, nullable=True,
+                               spark_layout=True, shuffle_seed=5)
+    groups = sum(pq.ParquetFile(p).metadata.num_row_groups for p in paths)
+    assert groups > 6
+    dump = tmp_path / "bits.bin"
+    p = run_cli("--input_uri", in_dir, "--output_uri", tmp_path / "unused", "--dump_bitset", dump,
+                "--num_reader_threads=6", check=True)
+    assert f"{groups} decode tasks" in p.stdout
+    got = np.fromfile(dump, dtype=np.uint64).reshape(n, -1)
+    assert np.array_equal(got, oracle.bitset_from_genotypes(geno))
+    # enough files for the threads: whole files, as before
+    p = run_cli("--input_uri", in_dir, "--output_uri", tmp_path / "unused", "--dump_bitset", dump,
+                "--num_reader_threads=2", check=True)
+    assert "2 decode tasks" in p.stdout
+    assert np.array_equal(np.fromfile(dump, dtype=np.uint64).reshape(n, -1), got)
 
 
 def test_null_genotypes_are_missing_and_bad_inputs_fail(tmp_path, oracle):
@@ -487,6 +592,94 @@ def test_rccl_path_shards_overflow_and_bad_gpu_count(c0, oracle):
     p = run_cli("--input_uri", c0["dir"] / "in", "--output_uri", c0["dir"] / "out_mg_bad",
                 "--num_gpus=64")
     assert p.returncode == 1 and "INVALID_ARGUMENT" in p.stderr and "GPU(s) are visible" in p.stderr
+
+
+# The N > 1 branch of the C++ multi-GPU host on ONE GPU: `--collectives=loopback`
+# swaps RCCL for device-to-device copies + host rendezvous (host/collectives.h),
+# so that three rank threads run RankMain's real schedule, gather offsets, cap on
+# the total and agreement on failures (RCCL itself refuses two ranks per device).
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [
+    ["--multi_gpu_mode=staged", "--bcast_chunks=3"],
+    ["--multi_gpu_mode=simple"],
+    ["--multi_gpu_mode=simple", "--calibration_tiles=2"],
+    ["--multi_gpu_mode=simple", "--rank_weights=1,3,2"],
+    ["--multi_gpu_mode=staged", "--pack=device", "--bcast_chunks=5"],
+    ["--kernel=stream"],
+])
+def test_three_ranks_on_one_gpu_through_the_loopback(c0, oracle, extra):
+    out = c0["dir"] / ("out_lb_" + "_".join(a.strip("-").replace("=", "_").replace(",", "_")
+                                            for a in extra))
+    p = run_cli("--input-uri", c0["dir"] / "in", "--output-uri", out, "--kin-threshold=0.05",
+                "--num_reader_threads=8", "--num_gpus=3", "--collectives=loopback", "--pack=host",
+                *extra, check=True)
+    exp = expected_table(oracle, c0["geno"], c0["ids"], 0.05)
+    check_output(out / "part-00000.snappy.parquet", exp, c0["ids"])
+    s = json.loads(p.stdout.strip().splitlines()[-1])
+    assert s["gpus"] == 3 and s["collectives"] == "loopback" and s["results"] == len(exp)
+    assert sum(s["rank_results"]) == len(exp) and len(s["rank_results"]) == 3
+    # nothing allocated, nothing waited for, once the first broadcast was enqueued
+    assert s["allocations_after_reserve"] == [0, 0, 0], s
+    assert s["host_syncs_after_reserve"] == [0, 0, 0], s
+    if "--kernel=stream" in extra:
+        assert s["rank_results"][1:] == [0, 0]
+        return
+    if "--multi_gpu_mode=simple" in extra:
+        ranges = s["rank_tile_ranges"]
+        num_tiles = cuking_amd._lib.load().cuking_num_tiles(
+            None, __import__("ctypes").byref(cuking_amd.Submatrix(1000).c))
+        if "--calibration_tiles=2" in extra:
+            assert s["calibration_tiles"] == 2 and len(s["rank_rates_tiles_per_ms"]) == 3
+            assert all(r > 0 for r in s["rank_rates_tiles_per_ms"])
+            assert ranges[0][0] == 6                      # behind the three calibration ranges
+        else:
+            assert s["calibration_tiles"] == 0 and ranges[0][0] == 0
+        assert ranges[-1][1] == num_tiles
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        if "--rank_weights=1,3,2" in extra:
+            sizes = [b - a for a, b in ranges]
+            assert sizes[1] > sizes[2] > sizes[0]
+    # every rank found something in this cohort's staged / ranged share, or at least ran
+    assert len(s["rank_kernel_ms"]) == 3 and all(ms > 0 for ms in s["rank_kernel_ms"])
+
+
+@pytest.mark.gpu
+def test_loopback_ranks_overflow_failures_and_shards(c0, oracle):
+    base = ["--input_uri", c0["dir"] / "in", "--num_gpus=3", "--collectives=loopback",
+            "--num_reader_threads=8"]
+    # The total over the ranks exceeds --max_results although every rank stays
+    # under it: the reference's error (cuking.cu:747-751), whatever the GPU count.
+    # (threshold 0: about half of the 499,500 pairs pass, spread over all ranks)
+    total = len(expected_table(oracle, c0["geno"], c0["ids"], 0.0))
+    assert total > 100_000
+    ok = run_cli(*base, "--output_uri", c0["dir"] / "out_lb_cap2", "--kin_threshold=0.0",
+                 f"--max_results={total}", "--multi_gpu_mode=simple", check=True)
+    s2 = json.loads(ok.stdout.strip().splitlines()[-1])
+    assert s2["results"] == total and sum(s2["rank_results"]) == total
+    assert max(s2["rank_results"]) < total - 1 and min(s2["rank_results"]) > 0, s2["rank_results"]
+    p = run_cli(*base, "--output_uri", c0["dir"] / "out_lb_cap3", "--kin_threshold=0.0",
+                f"--max_results={total - 1}", "--multi_gpu_mode=simple")
+    assert p.returncode == 1
+    assert ("Error: RESOURCE_EXHAUSTED: Could not store all results: try increasing "
+            "the --max_results parameter.") in p.stderr
+    assert not (c0["dir"] / "out_lb_cap3" / "part-00000.snappy.parquet").exists()
+    # A failure on ONE rank ends the job on all of them, in every phase and in
+    # both schedules: exit 1 with that rank's message, no hang, no output file.
+    for mode in ("staged", "simple"):
+        for phase in ("setup", "compute", "gather"):
+            out = c0["dir"] / f"out_lb_fail_{mode}_{phase}"
+            p = run_cli(*base, "--output_uri", out, "--kin_threshold=0.05",
+                        f"--multi_gpu_mode={mode}", f"--inject_failure=1:{phase}")
+            assert p.returncode == 1, (mode, phase, p.stdout, p.stderr)
+            assert f"rank 1: injected failure in phase {phase}" in p.stderr
+            assert not (out / "part-00000.snappy.parquet").exists()
+    # an off-diagonal shard over three ranks (simple schedule)
+    out = c0["dir"] / "out_lb_split"
+    p = run_cli(*base, "--output_uri", out, "--split_factor=2", "--shard_index=1",
+                "--kin_threshold=0.05", check=True)
+    check_output(out / "part-00001.snappy.parquet",
+                 expected_table(oracle, c0["geno"], c0["ids"], 0.05, 2, 1), c0["ids"])
+    assert json.loads(p.stdout.strip().splitlines()[-1])["multi_gpu_mode"] == "simple"
 
 
 @pytest.mark.gpu
