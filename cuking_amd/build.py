@@ -21,6 +21,10 @@ INCLUDE = ROOT / "include"
 
 LIB_PATH = PKG / "libcuking_amd.so"
 CLI_PATH = PKG / "bin" / "cuking"
+# The non-default flags the library next to it was built with ("" = the shipped
+# configuration).  Experiment scripts rebuild the library in place with extra
+# -D flags; the next default build must not mistake that file for its own.
+LIB_FLAGS_PATH = PKG / "libcuking_amd.flags"
 
 HIP_SOURCES = ["king_abi.hip", "king_kernels.hip", "king_mfma.hip", "synth.hip"]
 # Host-only half of the ABI: plain C++, also compiled by the sanitizer tests.
@@ -63,14 +67,18 @@ def build_library(force: bool = False, save_temps: bool = False,
     deps = srcs + [CSRC / "king_common.h", CSRC / "king_device.h", CSRC / "king_host.h",
                    CSRC / "king_submatrix.h", INCLUDE / "cuking_amd.h",
                    Path(__file__)]
-    if not force and _newer(LIB_PATH, deps):
+    extra = (["-DCUKING_TUNING"] if tuning else []) + \
+        os.environ.get("CUKING_EXTRA_HIPFLAGS", "").split()
+    wanted = " ".join(extra)
+    # (no stamp = a library from before stamps existed, or a box the stamp did not
+    #  travel to: trusted; a stamp that says something else = somebody's experiment)
+    stamped = LIB_FLAGS_PATH.read_text().strip() if LIB_FLAGS_PATH.exists() else wanted
+    if not force and _newer(LIB_PATH, deps) and stamped == wanted:
         return LIB_PATH
     cmd = [_hipcc(), *HIP_FLAGS, "-shared", f"-I{INCLUDE}", f"-I{CSRC}",
            *map(str, srcs), "-o", str(LIB_PATH)]
-    if tuning:
-        cmd.insert(1, "-DCUKING_TUNING")
     # experiments: extra -D flags, e.g. CUKING_EXTRA_HIPFLAGS="-DCUKING_MFMA_STAGES=3"
-    for flag in os.environ.get("CUKING_EXTRA_HIPFLAGS", "").split():
+    for flag in extra:
         cmd.insert(1, flag)
     # Always with -save-temps (in build_tmp/): the assembly of the matrix-core
     # kernel is checked below.  --save-temps adds the resource-usage remarks on the
@@ -94,6 +102,7 @@ def build_library(force: bool = False, save_temps: bool = False,
                            "accesses inside an LDS-DMA loop:\n  " + "\n  ".join(problems))
     for line in problems:
         print("warning (experiment build):", line, file=sys.stderr)
+    LIB_FLAGS_PATH.write_text(wanted + "\n")
     return LIB_PATH
 
 

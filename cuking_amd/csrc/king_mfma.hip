@@ -77,7 +77,7 @@ constexpr bool kPairedSync = CUKING_MFMA_PAIRED != 0 && kStages == 6;
 // even, 8 or 10.  10 x 16 KiB is the CU's whole LDS and puts 5.5 instead of 3.5
 // k-steps between a request and the hand-over that needs it: configs[2] 593 ->
 // 590 ms, 40k x 100k 95.2 -> 94.7 ms, configs[1] (bitset in the Infinity Cache) equal
-// (tools/exp25.sh).
+// (tools/experiments/exp25.sh).
 #define CUKING_MFMA_PAIRED_STAGES 10
 #endif
 constexpr int kStagesPaired = CUKING_MFMA_PAIRED_STAGES;
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     [[maybe_unused]] int stamp_row = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
 #endif
-    // Where a k-step's LDS reads of the NEXT k-step go (tools/exp14.sh, one box,
+    // Where a k-step's LDS reads of the NEXT k-step go (tools/experiments/exp14.sh, one box,
     // profiles/r02_mfma_stamps.txt): 0 = all eight in front of phase f = 3 (round
     // 1), 1 = in front of phase f = 2, 2 = phase f = 2, one behind each of its
     // first eight MFMAs (default), 3 = one per two MFMAs.
@@ -1305,7 +1305,7 @@ hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
   // CUKING_SPLIT_ROUNDS tiles per CU: 36 tiles 0.57 -> 0.25 ms, 300 tiles
   // 1.26 -> 0.91 ms, 820 tiles 2.40 -> 2.15 ms; configs[1] (3160 tiles = 12.3
   // rounds, the dispatcher's back-filling does not hide the 13th: time follows
-  // ceil(rounds), tools/exp15.sh) 6.93 -> 6.75 ms and 7.12 -> 6.84 ms on two
+  // ceil(rounds), tools/experiments/exp15.sh) 6.93 -> 6.75 ms and 7.12 -> 6.84 ms on two
   // boxes.  A piece costs ~30 us per tile it touches (slab, ticket) and the
   // pieces end as far apart as the whole tiles before them did (~0.3 ms after
   // 12 rounds), which is what is left of the ideal 0.66 x 0.53 ms

@@ -413,6 +413,13 @@ class GpuStagedOps:
         self.launches = 0
 
     def begin(self):
+        # Workspace (kernel layout, tile prefix, one split slab per stream) sized
+        # before anything is enqueued: no allocation, no device-wide wait once a
+        # broadcast is in flight (cuking_ctx_reserve).
+        if not getattr(self, "_reserved", False):
+            import torch
+            self.ctx.reserve(self.sm, self.wps, [torch.cuda.current_stream()] + self.streams)
+            self._reserved = True
         self.index_flag.zero_()
         self.launches = 0
 

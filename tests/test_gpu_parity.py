@@ -1001,3 +1001,133 @@ def test_wide_pair_with_4opp_beyond_2_24_on_the_gpu(ctx, kernel, variant):
         assert len(res) == 1 and res["kin"].view(np.uint32)[0] == ref.view(np.uint32)
         assert int(res["ibs0"][0]) == want["opposing_hom"]
     ctx.set_option("counts_mode", -1)
+
+
+def test_reserved_workspace_means_no_allocation_and_no_host_wait(oracle):
+    """cuking_ctx_reserve sizes the kernel layout, the tile prefix and the named
+    streams' split slabs up front; the compute / prepare calls for the block on
+    those streams then allocate nothing and never wait for the device (what a
+    host needs once collectives are in flight: host/multi_gpu.cc)."""
+    import torch
+    from cuking_amd.dist import staged_schedule, tile_partition
+    c = cuking_amd.KingContext(0)
+    try:
+        rng = np.random.default_rng(77)
+        n, m, thr = 700, 1500, 0.02
+        geno = random_genotypes(rng, n, m)
+        geno[n - 1] = geno[3]
+        sm = cuking_amd.Submatrix(n)
+        bits = oracle.bitset_from_genotypes(geno)
+        exp, _, _ = oracle.compute(oracle.submatrix(n), bits, thr)
+        d_bits = c.upload_bitset(bits)
+        wps = bits.shape[1]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        assert c.get_option("workspace_allocations") == 0
+        c.reserve(sm, wps, streams)
+        a0, s0 = c.get_option("workspace_allocations"), c.get_option("host_syncs")
+        assert a0 == 4                      # layout, prefix table, two slabs
+        c.reserve(sm, wps, streams)         # idempotent
+        assert c.get_option("workspace_allocations") == a0
+        results = torch.zeros((len(exp) + 8, 6), dtype=torch.int32, device="cuda:0")
+        idx = torch.zeros(2, dtype=torch.int32, device="cuda:0")
+
+        def records():
+            torch.cuda.synchronize()
+            cnt = int(idx[0])
+            assert int(idx[1]) == 0
+            r = results[:cnt].cpu().numpy().view(np.uint32).reshape(-1).view(
+                cuking_amd.KING_RESULT_DTYPE).copy()
+            idx.zero_()
+            torch.cuda.synchronize()
+            return cuking_amd.sort_results(r)
+
+        torch.cuda.synchronize()
+        for s in streams:                   # whole block, then tile ranges, on either stream
+            c.compute_king(sm, wps, d_bits, thr, len(exp) + 8, results, idx[0:1], idx[1:2], stream=s)
+            assert records().tobytes() == exp.tobytes()
+        for k, r in enumerate(tile_partition(c.num_tiles(sm), 3)):
+            c.compute_king(sm, wps, d_bits, thr, len(exp) + 8, results, idx[0:1], idx[1:2],
+                           stream=streams[k % 2], tile_range=r)
+        assert records().tobytes() == exp.tobytes()
+        c.invalidate()
+        for (c0, c1), rect in staged_schedule(n, c.tile_samples(), 1, 0, 3):   # staged form
+            c.prepare_samples(sm, wps, d_bits, c0, c1, stream=streams[0])
+            c.compute_king_rect(sm, wps, d_bits, rect[0], rect[1], thr, len(exp) + 8, results,
+                                idx[0:1], idx[1:2], stream=streams[0])
+        assert records().tobytes() == exp.tobytes()
+        # a smaller block fits the same workspace (only its prefix table is new data)
+        small = cuking_amd.Submatrix.from_ranges(0, 300, 0, 300)
+        exp_small, _, _ = oracle.compute(oracle.Submatrix(0, 300, 0, 300),
+                                         np.ascontiguousarray(bits[:300]), thr)
+        c.compute_king(small, wps, d_bits, thr, len(exp) + 8, results, idx[0:1], idx[1:2],
+                       stream=streams[1])
+        assert records().tobytes() == exp_small.tobytes()
+        assert c.get_option("workspace_allocations") == a0
+        # (the small block's new prefix table is one pageable upload that waits for
+        #  its own stream -- the only host-side wait since the reservation)
+        assert c.get_option("host_syncs") - s0 <= 1
+        with pytest.raises(cuking_amd.CukingError):
+            c.reserve(sm, wps, [torch.cuda.Stream() for _ in range(9)])
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("variant", [5, 0])
+def test_reuse_prepared_layout_and_invalidate(oracle, variant):
+    """Option "reuse_prepared": a repeated call on the same (block, width, shape,
+    bitset pointer) launches the pair kernel only; a host that rewrites the bitset
+    in place says so with cuking_invalidate().  Off (the default), every call
+    converts, like the reference's kernel reading the bitset as it is."""
+    import torch
+    c = cuking_amd.KingContext(0)
+    try:
+        c.set_option("variant", variant)
+        rng = np.random.default_rng(5)
+        n, m, thr = 400, 2000, 0.1
+        geno = random_genotypes(rng, n, m)
+        sm = cuking_amd.Submatrix(n)
+        bits = oracle.bitset_from_genotypes(geno)
+        before, _, _ = oracle.compute(oracle.submatrix(n), bits, thr)
+        d_bits = c.upload_bitset(bits)
+        wps = bits.shape[1]
+        geno2 = geno.copy()
+        geno2[7] = geno2[3]                      # sample 7 becomes a duplicate of sample 3
+        bits2 = oracle.bitset_from_genotypes(geno2)
+        after, _, _ = oracle.compute(oracle.submatrix(n), bits2, thr)
+        assert len(after) == len(before) + 1
+        c.timing_enable(True)
+        # default: every call converts and sees the bitset as it is
+        assert c.run(sm, wps, d_bits, thr).tobytes() == before.tobytes()
+        d_bits.copy_(torch.from_numpy(bits2.view(np.int64)))
+        assert c.run(sm, wps, d_bits, thr).tobytes() == after.tobytes()
+        assert c.timing_collect().prepare_launches == 2
+        # reuse: the second call launches no conversion
+        c.set_option("reuse_prepared", 1)
+        assert c.get_option("reuse_prepared") == 1
+        c.invalidate()
+        c.timing_reset()
+        d_bits.copy_(torch.from_numpy(bits.view(np.int64)))
+        torch.cuda.synchronize()
+        assert c.run(sm, wps, d_bits, thr).tobytes() == before.tobytes()
+        skipped = c.get_option("conversions_skipped")
+        assert c.run(sm, wps, d_bits, thr).tobytes() == before.tobytes()
+        assert c.run(sm, wps, d_bits, thr, tile_range=(0, c.num_tiles(sm))).tobytes() == before.tobytes()
+        t = c.timing_collect()
+        assert t.prepare_launches == 1 and t.king_launches >= 3
+        assert c.get_option("conversions_skipped") == skipped + 2
+        # in-place rewrite + invalidate: the new contents are converted and seen
+        d_bits.copy_(torch.from_numpy(bits2.view(np.int64)))
+        torch.cuda.synchronize()
+        c.invalidate()
+        c.timing_reset()
+        assert c.run(sm, wps, d_bits, thr).tobytes() == after.tobytes()
+        assert c.timing_collect().prepare_launches == 1
+        # another pointer, width or block is never taken for the prepared one
+        other = c.upload_bitset(bits)
+        assert c.run(sm, wps, other, thr).tobytes() == before.tobytes()
+        half = cuking_amd.Submatrix.from_ranges(0, 200, 0, 200)
+        exp_half, _, _ = oracle.compute(oracle.Submatrix(0, 200, 0, 200),
+                                        np.ascontiguousarray(bits[:200]), thr)
+        assert c.run(half, wps, other, thr).tobytes() == exp_half.tobytes()
+    finally:
+        c.close()
