@@ -57,9 +57,12 @@ if str(ROOT) not in sys.path:
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 # MI355X_MICROARCH.md, matrix cores: FP4 (block-scaled f8f6f4 MFMA) ~10 PF dense.
 MFMA_FP4_PEAK_TFLOPS = 10000.0
-# king_mfma.hip: plane products per pair and site, one multiply-add = 2 FLOP.
-MFMA_MACS_PER_PAIR_SITE = {"lean": 5, "full": 6}
-MFMA_VARIANT = 5
+# king_mfma.hip: plane products per pair and site, one multiply-add = 2 FLOP, by
+# kernel variant (5: five-product form on the quad layout; 6: four-product form
+# on the nibble layout).
+MFMA_MACS_PER_PAIR_SITE = {5: {"lean": 5, "full": 6}, 6: {"lean": 4, "full": 5}}
+MFMA_VARIANTS = (5, 6)
+MFMA_N4_MAX_SITES = 1 << 22
 NOMINAL_CLOCK_HZ = 2.4e9        # MI355X_MICROARCH.md: max clock
 NUM_SIMDS = 256 * 4
 # king_kernels.hip, per pair per 32 sites: lean form 5 logic + 4 v_bcnt (used
@@ -223,7 +226,7 @@ def counts_form(args, thr, wps, variant):
         return "full"
     if args.counts_mode == 0:
         return "lean"
-    c = 2.05 if args.kernel == "tiled" and variant == MFMA_VARIANT else 1.6
+    c = 2.05 if args.kernel == "tiled" and variant in MFMA_VARIANTS else 1.6
     return "lean" if thr > 0 and thr * thr * 32 * wps >= c * c else "full"
 
 
@@ -234,7 +237,9 @@ def roofline_block(args, ctx, *, launch_pairs, sites, wps, thr, king_ms, prepare
     import cuking_amd
     bpp = cuking_amd.bytes_per_pair(wps)
     variant = ctx.get_option("variant")
-    mfma = args.kernel == "tiled" and variant == MFMA_VARIANT and 32 * wps <= (1 << 24)
+    if variant == 6 and 32 * wps > MFMA_N4_MAX_SITES:
+        variant = 5          # (the library hands wider bitsets to the five-product form)
+    mfma = args.kernel == "tiled" and variant in MFMA_VARIANTS and 32 * wps <= (1 << 24)
     kernel_name = ("king_stream_kernel" if args.kernel == "stream" else
                    "king_mfma_kernel" if mfma else "king_tiled_kernel")
     form = counts_form(args, thr, wps, variant)
@@ -267,17 +272,24 @@ def roofline_block(args, ctx, *, launch_pairs, sites, wps, thr, king_ms, prepare
                                    if clock_mhz else None),
     }
     if mfma:
-        macs = MFMA_MACS_PER_PAIR_SITE[form]
-        tflops = (launch_pairs * sites * macs * 2 / (king_ms * 1e-3) / 1e12) if king_ms > 0 else 0.0
+        macs = MFMA_MACS_PER_PAIR_SITE[variant][form]
+        per_mac = (launch_pairs * sites * 2 / (king_ms * 1e-3) / 1e12) if king_ms > 0 else 0.0
+        tflops = per_mac * macs
+        # rounds 1-2 quoted the five-product form (5 / 6 products): the same time
+        # priced at that form's FLOP, for comparison across rounds
+        equiv = per_mac * MFMA_MACS_PER_PAIR_SITE[5][form]
         return {
             "bound": "mfma", "achieved": tflops, "peak": MFMA_FP4_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": tflops / MFMA_FP4_PEAK_TFLOPS, **common,
-            "form": form, "macs_per_pair_site": macs,
+            "form": form, "macs_per_pair_site": macs, "kernel_variant": variant,
+            "frac_five_product_equivalent": equiv / MFMA_FP4_PEAK_TFLOPS,
             "note": "fp4 (E2M1) v_mfma_f32_32x32x64_f8f6f4, exact integer sums in f32; "
-                    "algorithmic FLOP = pairs x sites x plane products x 2 (padding of "
-                    "tiles and of the last k-step not counted); peak = dense FP4 at the "
-                    "nominal 2.4 GHz, the chip holds less under this load "
-                    "(sustained_clock_mhz)",
+                    "algorithmic FLOP = pairs x sites x plane products the kernel issues x 2 "
+                    "(padding of tiles and of the last k-step not counted); `frac` is the "
+                    "share of the dense FP4 peak those products take, "
+                    "`frac_five_product_equivalent` prices the same time at the five-product "
+                    "form of rounds 1-2; peak at the nominal 2.4 GHz, the chip holds less "
+                    "under this load (sustained_clock_mhz)",
             "hbm": hbm_view,
         }
     roofline = {"bound": "hbm", **hbm_view, **common}

@@ -112,8 +112,8 @@ def check_mfma_loops(asm_path: Path, verbose: bool = False):
     such a loop (for a spill reload or a load of its own still in flight at loop
     entry) drains the whole prefetch pipeline every k-step -- 10 % of a launch the
     one time it happened (round 2, full form).  Returns the offending loops: blocks
-    with LDS-DMA and >= 40 MFMAs that hold a scratch instruction or a vmcnt wait
-    other than the hand-counted vmcnt(16)."""
+    with LDS-DMA and >= 16 MFMAs that hold a scratch instruction or a vmcnt wait
+    other than the hand-counted ones."""
     import re
     text = Path(asm_path).read_text()
     funcs = re.split(r"\n(?=_ZN6cuking12_GLOBAL__N_116king_mfma_kernel\w+:)", text)[1:]
@@ -121,8 +121,9 @@ def check_mfma_loops(asm_path: Path, verbose: bool = False):
         return [f"no king_mfma_kernel in {asm_path}"]
     problems = []
     for f in funcs:
-        m = re.match(r"_ZN6cuking12_GLOBAL__N_116king_mfma_kernelILb(\d)ELb(\d)ELi(\d)", f)
-        label = f"king_mfma_kernel<FULL={m.group(1)}, SPLIT={m.group(2)}, ABLATE={m.group(3)}>"
+        m = re.match(r"_ZN6cuking12_GLOBAL__N_116king_mfma_kernelILb(\d)ELb(\d)ELi(\d)ELb(\d)", f)
+        label = (f"king_mfma_kernel<FULL={m.group(1)}, SPLIT={m.group(2)}, ABLATE={m.group(3)}, "
+                 f"N4={m.group(4)}>")
         body = f.split(".Lfunc_end")[0]
         seen = 0
         for block in re.split(r"\n(?=\.LBB\d+_\d+:)", body):
@@ -136,13 +137,15 @@ def check_mfma_loops(asm_path: Path, verbose: bool = False):
                 continue
             loop = lines[:end + 1]
             mfma = sum("v_mfma" in l for l in loop)
-            if mfma < 40 or not any("global_load_lds" in l for l in loop):
-                continue  # (the full form's pass in front: compiler-counted loads, no LDS-DMA)
+            if mfma < 16 or not any("global_load_lds" in l for l in loop):
+                continue  # (the five-product full form's pass in front: compiler-counted loads, no LDS-DMA)
             seen += 1
             scratch = [l.strip() for l in loop if "scratch_" in l]
             waits = [l.strip() for l in loop if re.search(r"s_waitcnt.*vmcnt\(\d+\)", l)]
-            # (hand-counted: 16 = four stages in flight; 24 with CUKING_MFMA_PAIRED_STAGES=10)
-            foreign = [w for w in waits if "vmcnt(16)" not in w and "vmcnt(24)" not in w]
+            # (hand-counted: 16 = four stages in flight; 24 with CUKING_MFMA_PAIRED_STAGES=10;
+            #  20 = the four-product form's hand-over)
+            foreign = [w for w in waits
+                       if not any(f"vmcnt({n})" in w for n in (16, 20, 24))]
             if verbose:
                 print(f"{label}: loop {head} ({mfma} MFMAs): scratch {len(scratch)}, "
                       f"vmcnt waits {waits}")

@@ -159,10 +159,13 @@ int default_variant() {
 // variant with the same tile edge and k padding, so tile indices, tile bounds
 // and prepared ranges mean the same either way.
 int effective_variant(const cuking_ctx *ctx, uint32_t words_per_sample) {
-  if (ctx->variant == kMfmaVariant &&
-      (uint64_t)round_up(words_per_sample, 8) * 32 > kMfmaMaxSites)
-    return 2;
-  return ctx->variant;
+  const uint64_t sites = (uint64_t)round_up(words_per_sample, 8) * 32;
+  int v = ctx->variant;
+  // (the four-product variant decides on an integer that matches the
+  //  reference's float expression below 2^22 sites only)
+  if (v == kMfmaN4Variant && sites > kMfmaN4MaxSites) v = kMfmaVariant;
+  if (v == kMfmaVariant && sites > kMfmaMaxSites) v = 2;
+  return v;
 }
 
 // Which form of the tiled kernel.  The lean form keeps four sums per pair but
@@ -182,7 +185,7 @@ bool use_full_counts(const cuking_ctx *ctx, float kin_threshold, bool dense,
   if (ctx->counts_mode == 0) return false;
   if (!(kin_threshold > 0.0f)) return true;
   const double sites = 32.0 * words_per_sample;
-  const double c = effective_variant(ctx, words_per_sample) == kMfmaVariant ? 2.05 : 1.6;
+  const double c = is_mfma_variant(effective_variant(ctx, words_per_sample)) ? 2.05 : 1.6;
   return (double)kin_threshold * kin_threshold * sites < c * c;
 }
 
@@ -243,7 +246,7 @@ uint64_t total_tiles(const TileSpace &t) {
 cuking_status split_scratch_for(cuking_ctx *ctx, hipStream_t stream,
                                 uint32_t **scratch, uint32_t **counters) {
   *scratch = *counters = nullptr;
-  if (ctx->split_wgs == 0 || ctx->variant != kMfmaVariant) return CUKING_OK;
+  if (ctx->split_wgs == 0 || !is_mfma_variant(ctx->variant)) return CUKING_OK;
   const size_t bytes = mfma_split_scratch_bytes(ctx->split_wgs);
   uint32_t *base = nullptr;
   for (auto &e : ctx->split_scratch)
@@ -1130,7 +1133,7 @@ cuking_status cuking_ctx_reserve(cuking_ctx *ctx, const cuking_submatrix *sm,
   }
   if (num_streams > 8)
     return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "at most 8 streams per context can be reserved");
-  if (ctx->split_wgs != 0 && ctx->variant == kMfmaVariant) {
+  if (ctx->split_wgs != 0 && is_mfma_variant(ctx->variant)) {
     // (the slab cache holds 8 streams and drops ALL of them when a ninth comes:
     //  make room now rather than lose a slab reserved a moment ago)
     size_t missing = 0;

@@ -25,16 +25,28 @@ namespace cuking {
 // Padding samples and padding k-words are all-zero (= everything missing),
 // so they add nothing to any sum.
 //
-// Quad layout (kLayoutQuad, the matrix-core kernel): the reference's two bit
+// Quad layout (kLayoutQuad, the five-product matrix-core kernel): the reference's two bit
 // planes as they are, transposed: for every quad q of four consecutive 32-site
 // words, plane p (0 = het, 1 = hom_var, cuking.cu:507-511) and sample s one
 // uint4 holding those four words, planes[(q * 2 + p) * s_stride + s].  Half
 // the bytes of the word layout (2 bits per sample and site); the kernel derives
 // the A / R / H / D fragments with one three-input bit operation each.
 // Padding samples and k-words have both bits set (= missing).
+//
+// Nibble layout (kLayoutNibble, the four-product matrix-core kernel): ONE fp4
+// code per site, ready to be an MFMA operand after a single AND: for every
+// group j of 32 sites and sample s one uint4 of 32 nibbles,
+// planes[j * s_stride + s], site 32 j + 8 d + t in nibble t of dword d:
+//     bit 0  H   het                       (E2M1 0001 = 0.5)
+//     bit 1  D   defined                   (0010 = 1.0)
+//     bit 2  Y   hom-ref or hom-alt        (0100 = 2.0)
+//     bit 3  A   hom-alt: the SIGN of Y    (1100 = -2.0)
+// i.e. hom-ref 0110, het 0011, hom-alt 1110, missing / padding 0000.  4 bits per
+// sample and site = twice the bytes of the quad layout.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kLayoutWord = 0;
 constexpr uint32_t kLayoutQuad = 1;
+constexpr uint32_t kLayoutNibble = 2;
 
 struct PlaneGeometry {
   uint32_t num_rows, num_cols;        // block shape in samples
@@ -155,8 +167,8 @@ struct TiledArgs {
 __host__ __device__ inline size_t plane_bytes(const PlaneGeometry &g,
                                               uint32_t layout) {
   // word layout: 16 B per 32-site word and sample; quad layout: 2 x 16 B per
-  // four words and sample.
-  return (size_t)g.k_words * g.s_stride * (layout == 1 ? 8 : 16);
+  // four words and sample; nibble layout: 16 B per 32 sites and sample.
+  return (size_t)g.k_words * g.s_stride * (layout == kLayoutQuad ? 8 : 16);
 }
 
 // One compiled shape of the tiled kernel.
@@ -174,11 +186,21 @@ struct TiledVariant {
 constexpr uint32_t kMfmaMaxSites = 1u << 24;
 
 #ifdef CUKING_TUNING
-constexpr int kNumTiledVariants = 12;  // + timing-only experiments
+constexpr int kNumTiledVariants = 13;  // + timing-only experiments
 #else
-constexpr int kNumTiledVariants = 6;
+constexpr int kNumTiledVariants = 7;
 #endif
-constexpr int kMfmaVariant = 5;
+constexpr int kMfmaVariant = 5;    // five plane products, quad layout
+constexpr int kMfmaN4Variant = 6;  // four plane products, nibble layout (king_mfma.hip)
+// The four-product variant decides kinship on the integer num = hi + hj - 2 dd
+// + 2 q, which equals the reference's float expression while every partial sum
+// of that is exact, i.e. below 2^22 sites (include/cuking_amd.h, numerics
+// contract); wider bitsets take the five-product variant.
+constexpr uint32_t kMfmaN4MaxSites = 1u << 22;
+constexpr int kMfmaN4Stages = 5;
+constexpr uint32_t kMfmaN4LdsBytes = kMfmaN4Stages * 2 * 2 * 4 * 128 * 16;  // 5 x 32 KiB
+static_assert(kMfmaN4LdsBytes <= 160 * 1024, "LDS of one CU");
+inline bool is_mfma_variant(int v) { return v == kMfmaVariant || v == kMfmaN4Variant; }
 #ifndef CUKING_MFMA_STAGES
 #define CUKING_MFMA_STAGES 6
 #endif
@@ -195,7 +217,7 @@ const TiledVariant &tiled_variant(int v);
 hipError_t launch_tiled(int variant, bool full, const TiledArgs &args,
                         uint64_t num_tiles, hipStream_t stream);
 // The matrix-core kernel (king_mfma.hip); reached through launch_tiled.
-hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
+hipError_t launch_mfma(bool full, bool nibble, const TiledArgs &args, uint64_t num_tiles,
                        uint32_t lds_bytes, hipStream_t stream);
 // Bytes of split scratch (counters, then slabs) for `wgs` workgroups, and of
 // the counter part alone (the only part that must start out zero).

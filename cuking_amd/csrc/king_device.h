@@ -200,6 +200,53 @@ __device__ __forceinline__ bool kinship_may_pass(float het_i, float het_j,
   return q >= (threshold - 0.5f) - 1e-5f * (1.f + fabsf(q));
 }
 
+// The same decision from the numerator itself (four-product kernel: num = hi +
+// hj - 2 dd + 2 q as a float sum of exact terms, at most one rounding of 6e-8
+// relative; min_hets = min(hi, hj)).
+__device__ __forceinline__ bool kinship_may_pass_num(float num, float min_hets,
+                                                     float threshold) {
+  const float q = num * __builtin_amdgcn_rcpf(4.f * min_hets);
+  return q >= (threshold - 0.5f) - 1e-5f * (1.f + fabsf(q));
+}
+
+// Lean epilogue of the four-product kernel (king_mfma.hip): the main loop kept
+// hi, hj, dd = both defined and q = hom_hom - 2 opp.  Kinship's numerator
+// 2 bh - 4 opp - hi - hj (cuking.cu:291) equals hi + hj - 2 dd + 2 q; below 2^22
+// sites (kMfmaN4MaxSites) that integer is below 2^24 in magnitude like every
+// partial sum of the reference's float expression, so (float)num IS that
+// expression's value and kin comes out bit for bit the same.  bh and opp
+// themselves are only needed for the records: bh = hi + hj - dd + hom_hom and
+// opp = (hom_hom - q) / 2 from the recounted hom_hom.  Must be called by all 64
+// lanes.
+__device__ __forceinline__ void lean_epilogue_pair_n4(
+    const EmitCtx &a, bool valid, uint32_t li, uint32_t lj, uint32_t het_i,
+    uint32_t het_j, uint32_t dd, int32_t q, uint32_t lane) {
+  const uint32_t min_hets = het_i < het_j ? het_i : het_j;
+  const int32_t num = (int32_t)(het_i + het_j) - 2 * (int32_t)dd + 2 * q;
+  const float kin = 0.5f + (float)num / (4.f * (float)min_hets);
+  const bool emit = valid && kin > a.kin_threshold;
+  unsigned long long pending = __ballot(emit);  // wave-uniform
+  uint32_t hom_hom = 0;
+  while (pending) {
+    const int src = __builtin_ctzll(pending);
+    pending &= pending - 1;
+    const uint32_t p_li = __builtin_amdgcn_readlane(li, src);
+    const uint32_t p_lj = __builtin_amdgcn_readlane(lj, src);
+    const uint32_t off_j = a.diag ? p_lj : a.num_rows + p_lj;
+    const uint32_t sum =
+        wave_hom_hom_count(a.bits, a.words_per_sample, p_li, off_j, lane);
+    if ((int)lane == src) hom_hom = sum;
+  }
+  if (emit) {
+    const uint32_t both_het = het_i + het_j - dd + hom_hom;
+    const uint32_t opp = (uint32_t)((int32_t)hom_hom - q) >> 1;
+    const uint32_t ibs2 = hom_hom - opp + both_het;
+    emit_result(a.i_begin + li, a.j_begin + lj, kin, opp,
+                het_i + het_j - 2 * both_het, ibs2, a.max_results, a.results,
+                a.result_index, a.result_overflow);
+  }
+}
+
 // Full epilogue of one pair: all six reference sums from the five kept ones.
 __device__ __forceinline__ void full_epilogue_pair(
     const TiledArgs &a, bool valid, uint32_t li, uint32_t lj, uint32_t het_i,

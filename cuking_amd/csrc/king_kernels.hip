@@ -143,6 +143,74 @@ __global__ __launch_bounds__(256) void prepare_quads_kernel(
   }
 }
 
+// Same transpose into the nibble layout of the four-product matrix-core kernel
+// (king_common.h): one uint4 = the 32 sites of one 32-bit word of the reference
+// planes, one fp4 code per site.
+__device__ __forceinline__ uint32_t spread8(uint32_t b) {
+  // bit t of the low byte -> bit 4 t
+  uint32_t x = b & 0xFFu;
+  x = (x | (x << 12)) & 0x000F000Fu;
+  x = (x | (x << 6)) & 0x03030303u;
+  x = (x | (x << 3)) & 0x11111111u;
+  return x;
+}
+
+__global__ __launch_bounds__(256) void prepare_nibbles_kernel(
+    const uint64_t *__restrict__ bits, uint32_t words_per_sample,
+    PlaneGeometry geo, uint4 *__restrict__ planes, uint32_t s_tile_begin) {
+  __shared__ uint64_t het_lds[kPrepSamples][kPrepWords + 1];
+  __shared__ uint64_t hom_lds[kPrepSamples][kPrepWords + 1];
+
+  const uint32_t plane_words = words_per_sample / 2;
+  const uint32_t s0 = (s_tile_begin + blockIdx.x) * kPrepSamples;
+  const uint32_t w0 = blockIdx.y * kPrepWords;
+
+#pragma unroll
+  for (int it = 0; it < kPrepSamples * kPrepWords / 256; ++it) {
+    const uint32_t idx = it * 256 + threadIdx.x;
+    const uint32_t s = idx / kPrepWords, w = idx % kPrepWords;
+    const uint32_t ps = s0 + s;
+    uint32_t src = 0xFFFFFFFFu;
+    if (geo.diag || ps < geo.rows_padded) {
+      if (ps < geo.num_rows) src = ps;
+    } else {
+      const uint32_t c = ps - geo.col_base;
+      if (c < geo.num_cols) src = geo.num_rows + c;
+    }
+    uint64_t het = ~0ull, hom = ~0ull;  // missing
+    if (src != 0xFFFFFFFFu && w0 + w < plane_words) {
+      const uint64_t *p = bits + (uint64_t)src * words_per_sample + (w0 + w);
+      het = p[0];
+      hom = p[plane_words];
+    }
+    het_lds[s][w] = het;
+    hom_lds[s][w] = hom;
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int it = 0; it < kPrepSamples * kPrepWords * 2 / 256; ++it) {
+    const uint32_t idx = it * 256 + threadIdx.x;
+    const uint32_t krow = idx / kPrepSamples, s = idx % kPrepSamples;
+    const uint32_t k = w0 * 2 + krow;
+    if (k >= geo.k_words || s0 + s >= geo.s_stride) continue;
+    const uint32_t shift = (krow & 1) * 32;
+    const uint32_t het = (uint32_t)(het_lds[s][krow >> 1] >> shift);
+    const uint32_t hom = (uint32_t)(hom_lds[s][krow >> 1] >> shift);
+    uint32_t out[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint32_t hs = spread8(het >> (8 * d)), ms = spread8(hom >> (8 * d));
+      const uint32_t H = hs & ~ms;                 // het and defined
+      const uint32_t D = 0x11111111u ^ (hs & ms);  // defined
+      const uint32_t Y = 0x11111111u ^ hs;         // hom-ref or hom-alt
+      const uint32_t A = ms & ~hs;                 // hom-alt
+      out[d] = H | (D << 1) | (Y << 2) | (A << 3);
+    }
+    planes[(uint64_t)k * geo.s_stride + s0 + s] = make_uint4(out[0], out[1], out[2], out[3]);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // king_tiled_kernel
 //
@@ -594,6 +662,9 @@ const TiledVariant kVariants[kNumTiledVariants] = {
     // Matrix cores: 128 x 128 pairs per workgroup, 256 sites per k-step,
     // 16 KiB LDS stages (king_mfma.hip).
     {"t128_mfma_fp4", 128, 8, 256, kMfmaLdsBytes, kLayoutQuad},
+    // Matrix cores, four plane products on one fp4 code per site: 32 KiB LDS
+    // stages (king_mfma.hip).
+    {"t128_mfma_fp4_n4", 128, 8, 256, kMfmaN4LdsBytes, kLayoutNibble},
 #ifdef CUKING_TUNING
     {"phased_both_barriers", 64, 16, 512, 2 * 2 * 16 * 64 * 16, kLayoutWord},
     {"phased_bar_before_popcount_only", 64, 16, 512, 2 * 2 * 16 * 64 * 16, kLayoutWord},
@@ -632,14 +703,15 @@ hipError_t launch_tiled(int variant, bool full, const TiledArgs &args,
     case 2: return CUKING_SHAPE(16, 32, 8, 4, 8, 2, 2);
     case 3: return CUKING_SHAPE(32, 32, 4, 4, 8, 2, 4);
     case 4: return CUKING_SHAPE(16, 16, 4, 4, 16, 2, 4);
-    case kMfmaVariant: return launch_mfma(full, args, num_tiles, lds, stream);
+    case kMfmaVariant: return launch_mfma(full, false, args, num_tiles, lds, stream);
+    case kMfmaN4Variant: return launch_mfma(full, true, args, num_tiles, lds, stream);
 #ifdef CUKING_TUNING
-    case 6: return CUKING_PHASED(16, 2);
-    case 7: return CUKING_PHASED(16, 3);
-    case 8: return CUKING_PHASED(8, 1);
-    case 9: return launch_variant<16, 16, 4, 4, 8, 2, 4, false, 1>(args, num_tiles, lds, stream);
-    case 10: return launch_variant<16, 16, 4, 4, 8, 2, 4, false, 2>(args, num_tiles, lds, stream);
-    case 11: return launch_variant<16, 16, 4, 4, 8, 1, 5, false, 4>(args, num_tiles, lds, stream);
+    case 7: return CUKING_PHASED(16, 2);
+    case 8: return CUKING_PHASED(16, 3);
+    case 9: return CUKING_PHASED(8, 1);
+    case 10: return launch_variant<16, 16, 4, 4, 8, 2, 4, false, 1>(args, num_tiles, lds, stream);
+    case 11: return launch_variant<16, 16, 4, 4, 8, 2, 4, false, 2>(args, num_tiles, lds, stream);
+    case 12: return launch_variant<16, 16, 4, 4, 8, 1, 5, false, 4>(args, num_tiles, lds, stream);
 #endif
     default: return hipErrorInvalidValue;
   }
@@ -660,6 +732,9 @@ hipError_t launch_prepare_planes(uint32_t layout, const uint64_t *d_bit_sets,
   if (grid.y == 0) return hipSuccess;
   if (layout == kLayoutQuad)
     prepare_quads_kernel<<<grid, dim3(256), 0, stream>>>(
+        d_bit_sets, words_per_sample, geo, d_planes, s_tile_begin);
+  else if (layout == kLayoutNibble)
+    prepare_nibbles_kernel<<<grid, dim3(256), 0, stream>>>(
         d_bit_sets, words_per_sample, geo, d_planes, s_tile_begin);
   else
     prepare_planes_kernel<<<grid, dim3(256), 0, stream>>>(

@@ -105,6 +105,16 @@ __device__ __forceinline__ v8i frag(const uint4 het, const uint4 hom, uint32_t m
   return r;
 }
 
+// Nibble layout: a fragment is the stored dwords masked to one kind's bits.
+__device__ __forceinline__ v8i nfrag(const uint4 w, uint32_t mask) {
+  v8i r = {0, 0, 0, 0, 0, 0, 0, 0};
+  r[0] = (int)(w.x & mask);
+  r[1] = (int)(w.y & mask);
+  r[2] = (int)(w.z & mask);
+  r[3] = (int)(w.w & mask);
+  return r;
+}
+
 __device__ __forceinline__ uint4 shr3(const uint4 w) {
   return make_uint4(w.x >> 3, w.y >> 3, w.z >> 3, w.w >> 3);
 }
@@ -128,6 +138,12 @@ __device__ __attribute__((noinline)) void lean_epilogue_call(
     const EmitCtx c, bool valid, uint32_t li, uint32_t lj, uint32_t het_i,
     uint32_t het_j, uint32_t both_het, uint32_t opp, uint32_t lane) {
   lean_epilogue_pair(c, valid, li, lj, het_i, het_j, both_het, opp, lane);
+}
+
+__device__ __attribute__((noinline)) void lean_epilogue_call_n4(
+    const EmitCtx c, bool valid, uint32_t li, uint32_t lj, uint32_t het_i,
+    uint32_t het_j, uint32_t dd, int32_t q, uint32_t lane) {
+  lean_epilogue_pair_n4(c, valid, li, lj, het_i, het_j, dd, q, lane);
 }
 
 // Full form: a wavefront reserves the slots for ALL records of its 64 x 64 pairs
@@ -243,17 +259,26 @@ __device__ __forceinline__ uint32_t split_owner(uint64_t u, uint64_t units,
 // runs the epilogue.
 // ABLATE (tuning builds, wrong results): 1 = no LDS-DMA, 2 = no barrier either,
 // 3 = epilogue reduced to one store per lane (prices the kinship/threshold pass).
-template <bool FULL, bool SPLIT, int ABLATE = 0>
+// N4 = the four-product form on the nibble layout (below, "Four products").
+template <bool FULL, bool SPLIT, int ABLATE = 0, bool N4 = false>
 __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
-  // Lean form: 8 LDS stages and ONE stage barrier per two k-steps (below); the
-  // full form parks its fifth sum in the LDS behind the stages and keeps 6
-  // stages with a barrier per k-step.
-  constexpr bool PAIRED = !FULL && kPairedSync;
-  constexpr int NSTAGE = PAIRED ? kStagesPaired : kStages;
-  constexpr int NQ = 4;              // sums of the main loop: opp, bh, hi, hj
-  constexpr int NSUM = FULL ? 5 : 4; // + hom_hom from the full form's extra pass
+  // Five-product form: the lean form has 10 LDS stages and ONE stage barrier per
+  // two k-steps (below); the full form parks its fifth sum in the LDS behind the
+  // stages and keeps 6 stages with a barrier per k-step.  Four-product form:
+  // 5 stages of 32 KiB, every sum in registers.
+  constexpr bool PAIRED = !N4 && !FULL && kPairedSync;
+  constexpr int NSTAGE = N4 ? kMfmaN4Stages : PAIRED ? kStagesPaired : kStages;
+  constexpr int NSUM = FULL ? 5 : 4; // sums per pair
+  // ... of which the main loop keeps NQ = 4 in its accumulators (five products:
+  // opp, bh, hi, hj; four products: hi / 2, hj / 2, dd, 4 q).  The full form's
+  // fifth sum, hom_hom, comes from a pass of its own in front of the main loop and
+  // waits for the epilogue PARKED in LDS (five products) or in 64 registers that
+  // the main loop does not touch (four products: `hh5`, as 4 hom_hom).
+  constexpr int NQ = 4;
+  constexpr bool PARKED = FULL && !N4;
+  constexpr bool HH5 = FULL && N4;
   constexpr int BI = 2;              // 32-row blocks of the wavefront
-  extern __shared__ uint4 lds[];  // [NSTAGE][side][k-group][plane][128]
+  extern __shared__ uint4 lds[];  // [NSTAGE][side][k-group][plane | slice][128]
 
   // Which tile (SPLIT: which piece) this workgroup takes.
   uint32_t bid = blockIdx.x;
@@ -458,7 +483,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   // lean form.  (Round 1's full form made two passes of six products over
   // 32-row blocks in the compiler's order: 10.3 ms at 10k x 100k against 7.0 ms
   // lean.)
-  if constexpr (FULL) {
+  if constexpr (PARKED) {
     constexpr int D = 4;  // k-steps in flight
     v16f hh[BI][2];
 #pragma unroll
@@ -556,15 +581,19 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   }
 
   v16f acc[BI][2][NQ];
-#pragma unroll
-  for (int bi = 0; bi < BI; ++bi)
-#pragma unroll
-    for (int bj = 0; bj < 2; ++bj)
-#pragma unroll
-      for (int q = 0; q < NQ; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[bi][bj][q][r] = 0.f;
+  v16f hh5[BI][2];  // (four products, full form)
   constexpr uint32_t half_rows = 0;
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int bi = 0; bi < BI; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[bi][bj][q][r] = 0.f;
+  };
+  if constexpr (!N4) zero_acc();  // (four products: behind the hom_hom pass)
 
   // Raw words of the k-step: [block][plane] for the row and the column side.
   uint4 A[BI][2], B[2][2];
@@ -621,6 +650,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   // landed: the same vmcnt(16) as the unpaired form.  (In general, N stages:
   // even k-steps request stage i + N - 1, odd ones i + N - 3, and the wait
   // leaves the N - 4 youngest stages in flight.)
+  if constexpr (!N4) {
   constexpr int kPrologueStages = PAIRED ? NSTAGE - 2 : NSTAGE - 1;
 #pragma unroll
   for (int st = 0; st < kPrologueStages; ++st) issue_stage(st, st);
@@ -810,6 +840,278 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     CUKING_MMA16(3, Y)
     CUKING_MMA4(3, Y)
   }
+  } else {
+    // ---- Four products ------------------------------------------------------
+    // With D = defined, H = het, Y = hom-ref or hom-alt, T = (hom-ref) - (hom-alt):
+    //     hi = H_i.D_j    hj = D_i.H_j    dd = D_i.D_j    q = T_i.T_j
+    // and  2 bh - 4 opp - hi - hj = hi + hj - 2 dd + 2 q   (kinship's numerator),
+    //      bh - hom_hom = hi + hj - dd,   hom_hom - 2 opp = q,
+    // so four MFMAs per block pair and 64 sites instead of five give the
+    // threshold decision (the minimum: {numerator, hi, hj} is not in the span of
+    // three rank-1 products), and one more sum -- hom_hom, recounted for the few
+    // emitted pairs (lean) or a fifth product Y_i.Y_j (full) -- gives bh and opp.
+    // T needs a sign: the nibble layout (king_common.h) stores one fp4 code per
+    // site, H at bit 0 (0.5), D at bit 1 (1.0), Y at bit 2 (2.0), hom-alt in the
+    // SIGN bit, so that every fragment is ONE v_and_b32 of a stored dword with a
+    // constant (T: 0xC -> +-2.0) -- no bit-position passes, no shifted copies, no
+    // block scales: all MFMAs are the unscaled instruction, and each product
+    // carries a constant power of two (hi, hj: 1/2; q, hom_hom: 4) that the
+    // epilogue takes out exactly.  Per k-step (256 sites, 4 slices of 64) and
+    // wavefront: 64 MFMAs, 192 v_and (3.0 per MFMA; five products: 80 / 288),
+    // 16 ds_read_b128, 8 LDS-DMA requests of 1 KiB (twice the bytes).
+    //
+    // Pipeline (per slice c = 16 or 20 MFMAs): fragments are NOT double
+    // buffered; a fragment kind is rebuilt for slice c + 1 in the MFMA group
+    // behind its last use in slice c (group order hi, hj, dd, q[, hom_hom]), the
+    // raw words of slice c + 1 sit in the second raw buffer, and the LDS reads of
+    // slice c + 2 go into the buffer slice c has finished with.
+    constexpr int kSliceU4 = kTile;                  // one slice of one (side, k-group)
+    constexpr int kStageN4 = 2 * 2 * 4 * kSliceU4;   // uint4 per stage (32 KiB)
+    uint32_t mT;
+    asm volatile("s_mov_b32 %0, 0xcccccccc" : "=s"(mT));
+    const uint32_t mH = m1, mD = m2, mY = m4;
+    // DMA: wavefront (side, k-group) fetches that quarter of a stage: 4 slices x
+    // 2 halves of 64 samples, 1 KiB each.  Slice c of k-step s is group
+    // 8 s + 4 kg + c of the layout.
+    const uint4 *const g_wave4 = (dma_side ? g_cols : g_rows) +
+                                 (uint64_t)(8 * k_first + 4 * dma_kg) * s_stride;
+    const uint32_t l_wave4 = (uint32_t)(uintptr_t)(lds_void_ptr)(
+        lds + ((dma_side * 2 + dma_kg) * 4) * kSliceU4);
+    struct N4Addr { const uint4 *src; uint32_t dst; };
+    auto n4_addr = [&](uint32_t step, uint32_t buf) {
+      N4Addr pa;
+      if (step >= num_steps) step = num_steps - 1;  // (clamped repeats: see piece_addr)
+      pa.src = g_wave4 + (uint64_t)step * 8 * s_stride;
+      pa.dst = l_wave4 + buf * (kStageN4 * 16);
+      asm volatile("" : "+s"(pa.src), "+s"(pa.dst));
+      return pa;
+    };
+    auto n4_issue = [&](const N4Addr &pa, int c, int half) {
+      if (ABLATE == 1 || ABLATE == 2) return;
+      const uint4 *src = pa.src + (uint64_t)c * s_stride;
+      const uint32_t dst = pa.dst + c * (kSliceU4 * 16);
+      if (half)
+        asm volatile(
+            "s_mov_b32 m0, %0\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2 offset:1024"
+            :
+            : "s"(dst), "v"(lane16), "s"(src)
+            : "memory", "m0");
+      else
+        asm volatile(
+            "s_mov_b32 m0, %0\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2"
+            :
+            : "s"(dst), "v"(lane16), "s"(src)
+            : "memory", "m0");
+    };
+    // Stage hand-over, once per k-step (in its third slice, before the first LDS
+    // read of the next stage).  Requests of this wavefront still in flight then:
+    // stages s + 1 .. s + 3 and the 4 requests of stage s + 4 that slices 0 and 1
+    // have issued; stage s + 1 has landed when all but the 20 youngest have.
+    auto n4_sync = [&]() {
+      if (ABLATE == 2) return;
+      __builtin_amdgcn_s_waitcnt(vmcnt_imm(2 * 8 + 4));
+      __syncthreads();
+    };
+    // Stages 0 .. NSTAGE - 2 requested, stage 0 landed.
+    auto n4_prologue = [&]() {
+#pragma unroll
+      for (int st = 0; st < NSTAGE - 1; ++st) {
+        const N4Addr pa0 = n4_addr(st, st);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) n4_issue(pa0, r >> 1, r & 1);
+      }
+      if (ABLATE != 2) {
+        __builtin_amdgcn_s_waitcnt(vmcnt_imm(3 * 8));
+        __syncthreads();
+      }
+    };
+
+    // This lane's operand rows inside a stage (uint4 units): rows / columns.
+    uint32_t row_off4 = (0 * 2 + g) * 4 * kSliceU4 + wr + lr;
+    uint32_t col_off4 = (1 * 2 + g) * 4 * kSliceU4 + wc + lr;
+    asm volatile("" : "+v"(row_off4), "+v"(col_off4), "+v"(lane16));
+    uint4 RA[2][BI], RB[2][2];  // raw words [raw buffer][block]
+    // fragment kinds: 0 H, 1 D, 2 T, 3 Y
+    v8i Fa[4][BI], Fb[4][2];
+#define N4_READ(RB_, BUF, C)                                                   \
+    {                                                                          \
+      const uint4 *l_rows_ = lds + (BUF) * kStageN4 + row_off4 + (C) * kSliceU4; \
+      const uint4 *l_cols_ = lds + (BUF) * kStageN4 + col_off4 + (C) * kSliceU4; \
+      _Pragma("unroll") for (int b = 0; b < BI; ++b) RA[RB_][b] = l_rows_[b * 32]; \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b) RB[RB_][b] = l_cols_[b * 32]; \
+    }
+// Fragment builds are plain ANDs: nothing orders them against the MFMA groups
+// but data.  Left alone, the compiler gathers every build that reads a raw
+// buffer into the group that first touches it (60 ANDs behind 4 MFMAs, none
+// behind the next 12).  N4_PIN passes values through an empty asm statement:
+// a build cannot move above the pin of its input nor below the pin of its
+// result, which ties it to the group it is written in.
+#define N4_PIN4(W) asm volatile("" : "+v"((W).x), "+v"((W).y), "+v"((W).z), "+v"((W).w));
+#define N4_PINF(F) asm volatile("" : "+v"((F)[0]), "+v"((F)[1]), "+v"((F)[2]), "+v"((F)[3]));
+#define N4_PIN_RAW_A(RB_) _Pragma("unroll") for (int b = 0; b < BI; ++b) N4_PIN4(RA[RB_][b])
+#define N4_PIN_RAW_B(RB_) _Pragma("unroll") for (int b = 0; b < 2; ++b) N4_PIN4(RB[RB_][b])
+#define N4_PIN_A(K) _Pragma("unroll") for (int b = 0; b < BI; ++b) N4_PINF(Fa[K][b])
+#define N4_PIN_B(K) _Pragma("unroll") for (int b = 0; b < 2; ++b) N4_PINF(Fb[K][b])
+#define N4_BUILD_A(K, RB_, MASK)                                               \
+    _Pragma("unroll") for (int b = 0; b < BI; ++b) Fa[K][b] = nfrag(RA[RB_][b], MASK);
+#define N4_BUILD_B(K, RB_, MASK)                                               \
+    _Pragma("unroll") for (int b = 0; b < 2; ++b) Fb[K][b] = nfrag(RB[RB_][b], MASK);
+// product Q = kind KA of the rows x kind KB of the columns, four block pairs
+#define N4_MMA(Q, KA, KB)                                                      \
+    _Pragma("unroll") for (int bi = 0; bi < BI; ++bi)                          \
+    _Pragma("unroll") for (int bj = 0; bj < 2; ++bj)                           \
+      acc[bi][bj][Q] = mma<1>(Fa[KA][bi], Fb[KB][bj], acc[bi][bj][Q]);
+// A group of four MFMAs that also carries the slice's two DMA requests (in gaps
+// of their own) and the H columns of the next slice.
+#define N4_DMA_GROUP(Q, K, NXT, C)                                             \
+    _Pragma("unroll") for (int r = 0; r < 2; ++r) {                            \
+      n4_issue(pa, C, r);                                                      \
+      acc[0][r][Q] = mma<1>(Fa[K][0], Fb[K][r], acc[0][r][Q]);                 \
+      __builtin_amdgcn_sched_barrier(0);                                       \
+    }                                                                          \
+    N4_PIN_RAW_B(NXT)                                                          \
+    N4_BUILD_B(0, NXT, mH)                                                     \
+    _Pragma("unroll") for (int r = 0; r < 2; ++r)                              \
+      acc[1][r][Q] = mma<1>(Fa[K][1], Fb[K][r], acc[1][r][Q]);                 \
+    CUKING_PACE(2, 4)                                                          \
+    N4_PIN_B(0)                                                                \
+    __builtin_amdgcn_sched_barrier(0);
+// A group that issues the LDS reads of the slice after next (behind the stage
+// hand-over if SYNC) and builds the H rows of the next slice.
+#define N4_READ_GROUP(Q, KA, KB, CUR, NXT, RBUF, RSLICE, SYNC)                 \
+    if (SYNC) n4_sync();                                                       \
+    N4_READ(CUR, RBUF, RSLICE)                                                 \
+    N4_PIN_RAW_A(NXT)                                                          \
+    N4_BUILD_A(0, NXT, mH)                                                     \
+    N4_MMA(Q, KA, KB)                                                          \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                         \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                       \
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                       \
+    }                                                                          \
+    N4_PIN_A(0)                                                                \
+    __builtin_amdgcn_sched_barrier(0);
+// The last group of a slice: D of the next slice, columns first (the next
+// slice's first MFMAs read them).
+#define N4_LAST_GROUP(Q, KA, KB, NXT)                                          \
+    N4_PIN_RAW_A(NXT) N4_PIN_RAW_B(NXT)                                        \
+    N4_BUILD_B(1, NXT, mD) N4_BUILD_A(1, NXT, mD)                              \
+    N4_MMA(Q, KA, KB)                                                          \
+    CUKING_PACE(4, 4)                                                          \
+    N4_PIN_B(1) N4_PIN_A(1)                                                    \
+    __builtin_amdgcn_sched_barrier(0);
+// One slice.  CUR / NXT: raw buffers of this and the next slice; (RBUF, RSLICE):
+// stage buffer and slice whose raw words are read into CUR once this slice is
+// through with them (the slice after next); C: which slice's two DMA requests
+// go out; SYNC: stage hand-over in front of the reads.
+#define N4_SLICE(CUR, NXT, RBUF, RSLICE, SYNC, C)                              \
+    {                                                                          \
+      /* hi = H_i.D_j; T of this slice from its own raw words */               \
+      N4_PIN_RAW_A(CUR) N4_PIN_RAW_B(CUR)                                      \
+      N4_BUILD_A(2, CUR, mT) N4_BUILD_B(2, CUR, mT)                            \
+      N4_MMA(0, 0, 1)                                                          \
+      CUKING_PACE(4, 4)                                                        \
+      N4_PIN_A(2) N4_PIN_B(2)                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                       \
+      /* hj = D_i.H_j */                                                       \
+      N4_READ_GROUP(1, 1, 0, CUR, NXT, RBUF, RSLICE, SYNC)                     \
+      /* dd = D_i.D_j */                                                       \
+      N4_DMA_GROUP(2, 1, NXT, C)                                               \
+      /* q = T_i.T_j */                                                        \
+      N4_LAST_GROUP(3, 2, 2, NXT)                                              \
+    }
+// One slice of the full form's hom_hom pass: 4 MFMAs Y_i.Y_j on the fragments the
+// slice before built, the two requests, the reads of the slice after next and
+// the Y fragments of the next slice.
+#define N4_YSLICE(CUR, NXT, RBUF, RSLICE, SYNC, C)                             \
+    {                                                                          \
+      _Pragma("unroll") for (int r = 0; r < 2; ++r) {                          \
+        n4_issue(pa, C, r);                                                    \
+        hh5[0][r] = mma<1>(Fa[3][0], Fb[3][r], hh5[0][r]);                     \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+      }                                                                        \
+      _Pragma("unroll") for (int r = 0; r < 2; ++r)                            \
+        hh5[1][r] = mma<1>(Fa[3][1], Fb[3][r], hh5[1][r]);                     \
+      __builtin_amdgcn_sched_barrier(0);                                       \
+      if (SYNC) n4_sync();                                                     \
+      N4_READ(CUR, RBUF, RSLICE)                                               \
+      N4_PIN_RAW_A(NXT) N4_PIN_RAW_B(NXT)                                      \
+      N4_BUILD_A(3, NXT, mY) N4_BUILD_B(3, NXT, mY)                            \
+      N4_PIN_A(3) N4_PIN_B(3)                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                       \
+    }
+    if constexpr (HH5) {
+      // Full form: hom_hom = Y_i.Y_j in a pass of its own over the same stages (a
+      // fifth product inside the main loop would need 320 accumulator registers:
+      // the compiler then shuffles 64 of them between the two halves of the
+      // register file around every MFMA).  Its 64 registers stay where they are
+      // while the main loop runs: that loop needs 256 + ~100.
+#pragma unroll
+      for (int bi = 0; bi < BI; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) hh5[bi][bj][r] = 0.f;
+      n4_prologue();
+      N4_READ(0, 0, 0)
+      N4_READ(1, 0, 1)
+      N4_BUILD_A(3, 0, mY) N4_BUILD_B(3, 0, mY)
+      uint32_t buf = 0;
+      N4Addr pa = n4_addr(NSTAGE - 1, NSTAGE - 1);
+      for (uint32_t step = 0; step < num_steps; ++step) {
+        const uint32_t nbuf = buf == NSTAGE - 1 ? 0 : buf + 1;
+        N4_YSLICE(0, 1, buf, 2, false, 0)
+        N4_YSLICE(1, 0, buf, 3, false, 1)
+        N4_YSLICE(0, 1, nbuf, 0, true, 2)
+        N4_YSLICE(1, 0, nbuf, 1, false, 3)
+        pa = n4_addr(step + NSTAGE, buf);
+        buf = nbuf;
+      }
+      // the clamped repeats have landed and nobody reads the stages any more,
+      // before the main loop's prologue overwrites them
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+      __syncthreads();
+    }
+    zero_acc();
+    n4_prologue();
+    N4_READ(0, 0, 0)
+    N4_READ(1, 0, 1)
+    N4_BUILD_A(0, 0, mH) N4_BUILD_B(0, 0, mH)
+    N4_BUILD_A(1, 0, mD) N4_BUILD_B(1, 0, mD)
+    uint32_t buf = 0;  // buffer of the k-step being multiplied
+    // k-step s requests stage s + NSTAGE - 1 into the buffer stage s - 1 left
+    // (all its reads were issued before the hand-over of k-step s - 1)
+    N4Addr pa = n4_addr(NSTAGE - 1, NSTAGE - 1);
+    CUKING_TL(2 + 5 * tl_seg)
+    for (uint32_t step = 0; step < num_steps; ++step) {
+      const uint32_t nbuf = buf == NSTAGE - 1 ? 0 : buf + 1;
+      N4_SLICE(0, 1, buf, 2, false, 0)
+      N4_SLICE(1, 0, buf, 3, false, 1)
+      N4_SLICE(0, 1, nbuf, 0, true, 2)
+      N4_SLICE(1, 0, nbuf, 1, false, 3)
+      pa = n4_addr(step + NSTAGE, buf);
+      buf = nbuf;
+    }
+#undef N4_READ
+#undef N4_PIN4
+#undef N4_PINF
+#undef N4_PIN_RAW_A
+#undef N4_PIN_RAW_B
+#undef N4_PIN_A
+#undef N4_PIN_B
+#undef N4_BUILD_A
+#undef N4_BUILD_B
+#undef N4_MMA
+#undef N4_DMA_GROUP
+#undef N4_READ_GROUP
+#undef N4_LAST_GROUP
+#undef N4_SLICE
+#undef N4_YSLICE
+  }
   // The clamped repeats of the last stage must have landed before the
   // workgroup's LDS goes away.
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
@@ -818,7 +1120,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
 
   // Full form: the fifth sum stays where the pass in front of the main loop
   // parked it (this lane's 16-byte slots) and is read block by block.
-  float4 *const park = reinterpret_cast<float4 *>(lds + NSTAGE * kStageU4) +
+  float4 *const park = reinterpret_cast<float4 *>(lds + (PARKED ? NSTAGE * kStageU4 : 0)) +
                        (size_t)wave * (4 * 4 * 64) + lane;
 #undef CUKING_LOAD_RAW
 #undef CUKING_EXPAND
@@ -864,6 +1166,11 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
                 v[1] = __float_as_uint(acc[bi][bj][q][4 * r4 + 1]);
                 v[2] = __float_as_uint(acc[bi][bj][q][4 * r4 + 2]);
                 v[3] = __float_as_uint(acc[bi][bj][q][4 * r4 + 3]);
+              } else if constexpr (HH5) {
+                v[0] = __float_as_uint(hh5[bi][bj][4 * r4]);
+                v[1] = __float_as_uint(hh5[bi][bj][4 * r4 + 1]);
+                v[2] = __float_as_uint(hh5[bi][bj][4 * r4 + 2]);
+                v[3] = __float_as_uint(hh5[bi][bj][4 * r4 + 3]);
               } else {
                 const float4 h = park[((bi * 2 + bj) * 4 + r4) * 64];
                 v[0] = __float_as_uint(h.x);
@@ -926,6 +1233,11 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
                 acc[bi][bj][q][4 * r4 + 1] += v.y;
                 acc[bi][bj][q][4 * r4 + 2] += v.z;
                 acc[bi][bj][q][4 * r4 + 3] += v.w;
+              } else if constexpr (HH5) {
+                hh5[bi][bj][4 * r4] += v.x;
+                hh5[bi][bj][4 * r4 + 1] += v.y;
+                hh5[bi][bj][4 * r4 + 2] += v.z;
+                hh5[bi][bj][4 * r4 + 3] += v.w;
               } else {
                 float4 &h = park[((bi * 2 + bj) * 4 + r4) * 64];
                 h = make_float4(h.x + v.x, h.y + v.y, h.z + v.z, h.w + v.w);
@@ -945,13 +1257,37 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
           for (int r = 0; r < 16; ++r) sum += acc[bi][bj][q][r];
-    if (FULL) sum += park[0].x;
+    if (PARKED) sum += park[0].x;
+    if (HH5) sum += hh5[0][0][0];
     if (sum == -1.f) a.results[0].kin = sum;  // never true, keeps the sums alive
     continue;
   }
   // --- epilogue: kinship, threshold, append (cuking.cu:284-313).  C layout of
   // the 32 x 32 MFMA: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
   const EmitCtx emit_ctx = make_emit_ctx(a);
+  // The five sums of pair (bi, bj, r) as integers.  Five products: they are the
+  // accumulators (hom_hom parked, `parked`).  Four products: hi / 2, hj / 2, dd,
+  // 4 q (and 4 hom_hom in hh5) are, and bh = hi + hj - dd + hom_hom,
+  // opp = (hom_hom - q) / 2.
+  auto pair_sums = [&](int bi, int bj, int r, float parked, uint32_t *het_i, uint32_t *het_j,
+                       uint32_t *both_het, uint32_t *opp, uint32_t *hom_hom) {
+    if constexpr (N4) {
+      *het_i = (uint32_t)(2.f * acc[bi][bj][0][r]);
+      *het_j = (uint32_t)(2.f * acc[bi][bj][1][r]);
+      const uint32_t dd = (uint32_t)acc[bi][bj][2][r];
+      const int32_t q = (int32_t)(0.25f * acc[bi][bj][3][r]);
+      const uint32_t hh = HH5 ? (uint32_t)(0.25f * hh5[bi][bj][r]) : 0u;  // (full form only)
+      *hom_hom = hh;
+      *both_het = *het_i + *het_j - dd + hh;
+      *opp = (uint32_t)((int32_t)hh - q) >> 1;
+    } else {
+      *het_i = (uint32_t)acc[bi][bj][2][r];
+      *het_j = (uint32_t)acc[bi][bj][3][r];
+      *both_het = (uint32_t)acc[bi][bj][1][r];
+      *opp = (uint32_t)acc[bi][bj][0][r];
+      *hom_hom = (uint32_t)parked;
+    }
+  };
   if (FULL && a.dense_counts == nullptr) {
     // Full form, records: sweep 0 decides every pair (cuking.cu:284-297) and
     // counts, ONE reservation for the wavefront's records, sweep 1 stores them
@@ -968,17 +1304,16 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
           const uint32_t lj = tc * kTile + wc + bj * 32 + lr;
 #pragma unroll
           for (int r4 = 0; r4 < 4; ++r4) {
-            const float4 h4 = park[((bi * 2 + bj) * 4 + r4) * 64];
+            const float4 h4 = PARKED ? park[((bi * 2 + bj) * 4 + r4) * 64]
+                                     : make_float4(0, 0, 0, 0);
             const float hh[4] = {h4.x, h4.y, h4.z, h4.w};
 #pragma unroll
             for (int r1 = 0; r1 < 4; ++r1) {
               const int r = 4 * r4 + r1;
               const uint32_t li =
                   tr * kTile + wr + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-              const uint32_t het_i = (uint32_t)acc[bi][bj][2][r];
-              const uint32_t het_j = (uint32_t)acc[bi][bj][3][r];
-              const uint32_t both_het = (uint32_t)acc[bi][bj][1][r];
-              const uint32_t opp = (uint32_t)acc[bi][bj][0][r];
+              uint32_t het_i, het_j, both_het, opp, hom_hom;
+              pair_sums(bi, bj, r, hh[r1], &het_i, &het_j, &both_het, &opp, &hom_hom);
               if (pass == 0) {
                 // cuking.cu:199 plus the tile padding
                 const bool valid = li < a.geo.num_rows && lj < a.geo.num_cols &&
@@ -996,7 +1331,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
                   run += (uint32_t)__popcll(b);
                   if (emit)
                     full_store_call(emit_ctx, slot, li, lj, het_i, het_j, both_het, opp,
-                                    (uint32_t)hh[r1]);
+                                    hom_hom);
                 }
               }
             }
@@ -1023,7 +1358,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       float hh[16];  // (full form) hom_hom of this block's 16 pairs
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        const float4 h = FULL ? park[((bi * 2 + bj) * 4 + r4) * 64] : make_float4(0, 0, 0, 0);
+        const float4 h = PARKED ? park[((bi * 2 + bj) * 4 + r4) * 64] : make_float4(0, 0, 0, 0);
         hh[4 * r4] = h.x;
         hh[4 * r4 + 1] = h.y;
         hh[4 * r4 + 2] = h.z;
@@ -1038,9 +1373,22 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
                            a.i_begin + li < a.j_begin + lj;
         if (FULL) {
           // diagnostic counts: cuking.cu:284-313 with all five sums at hand
-          full_epilogue_pair(a, valid, li, lj, (uint32_t)acc[bi][bj][2][r],
-                             (uint32_t)acc[bi][bj][3][r], (uint32_t)acc[bi][bj][1][r],
-                             (uint32_t)acc[bi][bj][0][r], (uint32_t)hh[r]);
+          uint32_t het_i, het_j, both_het, opp, hom_hom;
+          pair_sums(bi, bj, r, hh[r], &het_i, &het_j, &both_het, &opp, &hom_hom);
+          full_epilogue_pair(a, valid, li, lj, het_i, het_j, both_het, opp, hom_hom);
+        } else if constexpr (N4) {
+          // Four products, lean: the decision needs hi, hj and the numerator
+          // hi + hj - 2 dd + 2 q only; bh and opp of an emitted pair follow from
+          // the recount of hom_hom (king_device.h).
+          const float f_hi = 2.f * acc[bi][bj][0][r], f_hj = 2.f * acc[bi][bj][1][r];
+          const float f_num = f_hi + f_hj - 2.f * acc[bi][bj][2][r] + 0.5f * acc[bi][bj][3][r];
+          const bool maybe = !CUKING_MFMA_PREFILTER ||
+                             (valid && kinship_may_pass_num(f_num, fminf(f_hi, f_hj),
+                                                            a.kin_threshold));
+          if (__ballot(maybe) != 0)
+            lean_epilogue_call_n4(emit_ctx, valid, li, lj, (uint32_t)f_hi, (uint32_t)f_hj,
+                                  (uint32_t)acc[bi][bj][2][r],
+                                  (int32_t)(0.25f * acc[bi][bj][3][r]), lane);
         } else {
           // Nearly every pair fails the threshold: decide that on the float
           // sums without the IEEE divide, and only when some lane of the
@@ -1066,12 +1414,13 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   CUKING_TL(11)
 }
 
-template <bool FULL, bool SPLIT, int ABLATE = 0>
+template <bool FULL, bool SPLIT, int ABLATE = 0, bool N4 = false>
 hipError_t launch_shape(const TiledArgs &args, uint64_t num_blocks,
                         uint32_t lds_bytes, hipStream_t stream) {
-  auto kernel = king_mfma_kernel<FULL, SPLIT, ABLATE>;
-  // (the caller's figure is the 6-stage one of the variant table)
-  if (FULL) lds_bytes += kMfmaParkBytes;  // the parked fifth sum, behind the stages
+  auto kernel = king_mfma_kernel<FULL, SPLIT, ABLATE, N4>;
+  // (five products: the caller's figure is the 6-stage one of the variant table)
+  if (N4) lds_bytes = kMfmaN4LdsBytes;
+  else if (FULL) lds_bytes += kMfmaParkBytes;  // the parked fifth sum, behind the stages
   else if (kPairedSync) lds_bytes = kStagesPaired * kStageU4 * sizeof(uint4);
   static DeviceOnce attr_set;  // per device, see king_device.h
   if (!attr_set.done()) {
@@ -1286,13 +1635,38 @@ size_t mfma_split_scratch_bytes(uint32_t wgs) {
 }
 size_t mfma_split_counter_bytes(uint32_t wgs) { return split_counter_bytes(wgs); }
 
-hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
+namespace {
+// launch_shape<FULL, SPLIT, 0, N4> by run-time flags
+hipError_t launch_form(bool full, bool split, bool nibble, const TiledArgs &a, uint64_t blocks,
                        uint32_t lds_bytes, hipStream_t stream) {
-  if ((uint64_t)args.geo.k_words * 32 > kMfmaMaxSites) return hipErrorInvalidValue;
+  if (nibble) {
+    if (split)
+      return full ? launch_shape<true, true, 0, true>(a, blocks, lds_bytes, stream)
+                  : launch_shape<false, true, 0, true>(a, blocks, lds_bytes, stream);
+    return full ? launch_shape<true, false, 0, true>(a, blocks, lds_bytes, stream)
+                : launch_shape<false, false, 0, true>(a, blocks, lds_bytes, stream);
+  }
+  if (split)
+    return full ? launch_shape<true, true>(a, blocks, lds_bytes, stream)
+                : launch_shape<false, true>(a, blocks, lds_bytes, stream);
+  return full ? launch_shape<true, false>(a, blocks, lds_bytes, stream)
+              : launch_shape<false, false>(a, blocks, lds_bytes, stream);
+}
+}  // namespace
+
+hipError_t launch_mfma(bool full, bool nibble, const TiledArgs &args, uint64_t num_tiles,
+                       uint32_t lds_bytes, hipStream_t stream) {
+  if ((uint64_t)args.geo.k_words * 32 > (nibble ? kMfmaN4MaxSites : kMfmaMaxSites))
+    return hipErrorInvalidValue;
 #ifdef CUKING_TUNING
   // Timing-only experiments (wrong results): CUKING_MFMA_ABLATE=1 no LDS-DMA,
   // =2 no stage barrier either.
   if (const char *e = getenv("CUKING_MFMA_ABLATE")) {
+    if (nibble) {
+      if (e[0] == '1') return launch_shape<false, false, 1, true>(args, num_tiles, lds_bytes, stream);
+      if (e[0] == '2') return launch_shape<false, false, 2, true>(args, num_tiles, lds_bytes, stream);
+      if (e[0] == '3') return launch_shape<false, false, 3, true>(args, num_tiles, lds_bytes, stream);
+    }
     if (e[0] == '1') return launch_shape<false, false, 1>(args, num_tiles, lds_bytes, stream);
     if (e[0] == '2') return launch_shape<false, false, 2>(args, num_tiles, lds_bytes, stream);
     if (e[0] == '3') return launch_shape<false, false, 3>(args, num_tiles, lds_bytes, stream);
@@ -1340,8 +1714,7 @@ hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
     TiledArgs pa = args;
     pa.split_tiles = (uint32_t)num_tiles;
     pa.split_wgs = wgs | 0x80000000u;
-    return full ? launch_shape<true, true>(pa, wgs, lds_bytes, stream)
-                : launch_shape<false, true>(pa, wgs, lds_bytes, stream);
+    return launch_form(full, true, nibble, pa, wgs, lds_bytes, stream);
   }
 #endif
   if (getenv("CUKING_AMD_DEBUG"))
@@ -1351,9 +1724,7 @@ hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
   TiledArgs a = args;
   a.split_tiles = 0;
   a.split_whole = 0;
-  if (rest == 0)
-    return full ? launch_shape<true, false>(a, whole, lds_bytes, stream)
-                : launch_shape<false, false>(a, whole, lds_bytes, stream);
+  if (rest == 0) return launch_form(full, false, nibble, a, whole, lds_bytes, stream);
   // One launch: `head` whole-tile workgroups followed by the wgs pieces of the
   // remainder, so that CUs finishing their last whole tile go straight on to
   // pieces (a second launch would wait for the slowest whole tile first).
@@ -1364,24 +1735,21 @@ hipError_t launch_mfma(bool full, const TiledArgs &args, uint64_t num_tiles,
     // (test hook: a block limit below the piece count) whole tiles on their
     // own, in as many launches as it takes, then the pieces
     if (head != 0) {
-      const hipError_t e = full ? launch_shape<true, false>(a, head, lds_bytes, stream)
-                                : launch_shape<false, false>(a, head, lds_bytes, stream);
+      const hipError_t e = launch_form(full, false, nibble, a, head, lds_bytes, stream);
       if (e != hipSuccess) return e;
     }
     a.tile_begin = args.tile_begin + head;
     head = 0;
   } else if (head + wgs + wgs / 2 > cap) {  // (the pieces' launch has wgs / 2 spare workgroups)
     const uint64_t first = head + wgs + wgs / 2 - cap;
-    const hipError_t e = full ? launch_shape<true, false>(a, first, lds_bytes, stream)
-                              : launch_shape<false, false>(a, first, lds_bytes, stream);
+    const hipError_t e = launch_form(full, false, nibble, a, first, lds_bytes, stream);
     if (e != hipSuccess) return e;
     a.tile_begin = args.tile_begin + first;
     head -= first;
   }
   a.split_whole = (uint32_t)head;
   a.split_tiles = rest;
-  return full ? launch_shape<true, true>(a, head + wgs, lds_bytes, stream)
-              : launch_shape<false, true>(a, head + wgs, lds_bytes, stream);
+  return launch_form(full, true, nibble, a, head + wgs, lds_bytes, stream);
 }
 
 }  // namespace cuking

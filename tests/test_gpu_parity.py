@@ -18,7 +18,8 @@ from conftest import GOLDEN, random_genotypes
 
 pytestmark = pytest.mark.gpu
 
-NUM_VARIANTS = 6   # 0-4 VALU shapes, 5 matrix cores (cuking_variant_name)
+NUM_VARIANTS = 7   # 0-4 VALU shapes, 5 / 6 matrix cores: five / four products (cuking_variant_name)
+MFMA_VARIANTS = [5, 6]
 KERNELS = [("stream", 0)] + [("tiled", v) for v in range(NUM_VARIANTS)]
 
 
@@ -159,7 +160,7 @@ def test_lean_and_full_forms_agree_with_oracle(ctx, oracle, variant, counts_mode
     select(ctx, "tiled", 0)
 
 
-@pytest.mark.parametrize("kernel,variant", [("stream", 0), ("tiled", 0), ("tiled", 1), ("tiled", 5)])
+@pytest.mark.parametrize("kernel,variant", [("stream", 0), ("tiled", 0), ("tiled", 1), ("tiled", 5), ("tiled", 6)])
 @pytest.mark.parametrize("k", [2, 3, 4])
 def test_split_factor_shards(ctx, oracle, kernel, variant, k):
     """--split_factor / --shard_index (cuking.cu:46-52): every shard equals the
@@ -211,7 +212,7 @@ def test_tile_ranges_union(ctx, oracle, variant):
         ctx.run(sm, bits.shape[1], d_bits, -0.05, tile_range=(0, tiles + 1))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 4, 5, 6])
 @pytest.mark.parametrize("world,chunks", [(1, 1), (1, 4), (2, 3), (3, 8), (8, 5)])
 def test_staged_rectangles_union(ctx, oracle, variant, world, chunks):
     """The overlapped multi-GPU schedule (chunked arrival, row bands, rectangle
@@ -272,7 +273,7 @@ def test_staged_api_errors(ctx, oracle):
                               res, idx[0:1], idx[1:2])
 
 
-@pytest.mark.parametrize("kernel,variant", [("stream", 0), ("tiled", 0), ("tiled", 5)])
+@pytest.mark.parametrize("kernel,variant", [("stream", 0), ("tiled", 0), ("tiled", 5), ("tiled", 6)])
 def test_result_overflow(ctx, oracle, kernel, variant):
     """cuking.cu:297-313, :747-751: overflow is an error, never truncation."""
     import torch
@@ -303,7 +304,7 @@ def test_result_overflow(ctx, oracle, kernel, variant):
     assert got.tobytes() == exp.tobytes()
 
 
-@pytest.mark.parametrize("kernel,variant", [("stream", 0), ("tiled", 0), ("tiled", 2), ("tiled", 5)])
+@pytest.mark.parametrize("kernel,variant", [("stream", 0), ("tiled", 0), ("tiled", 2), ("tiled", 5), ("tiled", 6)])
 def test_long_ranges_are_split_into_several_launches(ctx, oracle, kernel, variant):
     """One launch may not exceed 2^32 - 1 threads (beyond that HIP truncates
     silently): long tile / pair ranges go out as several launches.  The cap is
@@ -325,13 +326,14 @@ def test_long_ranges_are_split_into_several_launches(ctx, oracle, kernel, varian
         ctx.set_option("max_launch_blocks", 0)
 
 
+@pytest.mark.parametrize("mv", MFMA_VARIANTS)
 @pytest.mark.parametrize("thr,counts_mode", [(0.1, -1), (-1e30, 0), (-1e30, 1)])
-def test_matrix_core_remainder_split(ctx, oracle, thr, counts_mode):
+def test_matrix_core_remainder_split(ctx, oracle, thr, counts_mode, mv):
     """The matrix-core variant cuts a remainder of tiles (fewer than one per CU)
     into equal pieces of k-steps over all CUs; partial sums meet in a scratch
     slab.  `split_wgs` stands in for the CU count so that a small block
     exercises pieces that span tile boundaries, whole tiles and no split."""
-    select(ctx, "tiled", 5, counts_mode)
+    select(ctx, "tiled", mv, counts_mode)
     rng = np.random.default_rng(99)
     n, m = 700, 9000
     geno = random_genotypes(rng, n, m, missing=0.03)
@@ -360,13 +362,18 @@ def test_matrix_core_remainder_split(ctx, oracle, thr, counts_mode):
         select(ctx, "tiled", 0)
 
 
-@pytest.mark.parametrize("sites,expect_fallback", [((1 << 24) - 256, False), ((1 << 24) + 512, True)])
-def test_matrix_core_float_limit(ctx, oracle, sites, expect_fallback):
-    """The matrix-core variant counts in float32: exact while every sum stays
+@pytest.mark.parametrize("mv,sites", [(5, (1 << 24) - 256), (5, (1 << 24) + 512),
+                                      (6, (1 << 22) - 256), (6, (1 << 22) + 512),
+                                      (6, (1 << 24) + 512)])
+def test_matrix_core_float_limit(ctx, oracle, mv, sites):
+    """The matrix-core variants count in float32: exact while every sum stays
     below 2^24.  Just under the limit with sums as large as they get (every
     site het in every sample) it must still be bit-exact; just over it the
-    library switches to the VALU variant with the same tile geometry."""
-    select(ctx, "tiled", 5)
+    library switches to the VALU variant with the same tile geometry.  The
+    four-product variant decides kinship on an integer that equals the reference's
+    float expression below 2^22 sites: from there on it hands over to the
+    five-product one."""
+    select(ctx, "tiled", mv)
     n = 20
     wps = cuking_amd.words_per_sample(sites)
     rng = np.random.default_rng(3)
@@ -388,7 +395,7 @@ def test_matrix_core_float_limit(ctx, oracle, sites, expect_fallback):
     select(ctx, "tiled", 0)
 
 
-@pytest.mark.parametrize("kernel,variant", [("tiled", 5), ("tiled", 0), ("stream", 0)])
+@pytest.mark.parametrize("kernel,variant", [("tiled", 5), ("tiled", 6), ("tiled", 0), ("stream", 0)])
 def test_site_position_patterns(ctx, oracle, kernel, variant):
     """Genotype patterns that single out one site position: the matrix-core
     kernel expands sites by their position inside a 4-site nibble (position 3 is
@@ -719,7 +726,7 @@ def test_rect_needs_prepared_samples(ctx, oracle):
     call has converted for a different block since, are FAILED_PRECONDITION,
     not silently wrong sums."""
     import torch
-    for variant in (0, 5):
+    for variant in (0, 5, 6):
         select(ctx, "tiled", variant)
         tile = ctx.tile_samples()
         n = 5 * tile - 17
@@ -762,7 +769,7 @@ def test_rect_needs_prepared_samples(ctx, oracle):
         assert ovf == 0 and got.tobytes() == whole.tobytes() == exp.tobytes()
 
 
-@pytest.mark.parametrize("variant", [0, 5])
+@pytest.mark.parametrize("variant", [0, 5, 6])
 def test_calls_on_two_streams_of_one_context(ctx, oracle, variant):
     """Two blocks back to back on two non-blocking streams of ONE context: the
     second call's layout conversion overwrites the workspace the first call's
@@ -799,12 +806,13 @@ def test_calls_on_two_streams_of_one_context(ctx, oracle, variant):
             assert ovf == 0 and got.tobytes() == exp.tobytes(), rounds
 
 
+@pytest.mark.parametrize("mv", MFMA_VARIANTS)
 @pytest.mark.parametrize("split_wgs", [0, 256])
-def test_tile_order_options_do_not_change_results(ctx, oracle, split_wgs):
+def test_tile_order_options_do_not_change_results(ctx, oracle, split_wgs, mv):
     """XCD-aware workgroup order and band height only permute which workgroup
     evaluates which tile: records, tile-range unions and rectangles stay the
     oracle's for every setting (launches of >= 64 tiles take the XCD order)."""
-    select(ctx, "tiled", 5)
+    select(ctx, "tiled", mv)
     ctx.set_option("split_wgs", split_wgs)
     rng = np.random.default_rng(99)
     n, m = 2700, 700                       # 22 tile rows: 253 tiles
@@ -842,11 +850,13 @@ def test_tile_order_options_do_not_change_results(ctx, oracle, split_wgs):
         ctx.set_option("split_wgs", 256)
 
 
-def test_dynamic_tail_of_a_launch(ctx, oracle):
+@pytest.mark.parametrize("mv", MFMA_VARIANTS)
+def test_dynamic_tail_of_a_launch(ctx, oracle, mv):
     """Launches of many rounds hand their last tiles out through a counter
     (king_common.h, dyn_tiles): the same records as the static order, launch after
     launch (the counter returns to zero), in both forms, with the launch cut into
     several by the block limit, and for tile sub-ranges."""
+    select(ctx, "tiled", mv)
     rng = np.random.default_rng(77)
     n, m = 6000, 500                       # 47 tile rows: 1128 tiles
     geno = random_genotypes(rng, n, m, missing=0.03)
@@ -906,8 +916,9 @@ def test_dynamic_tail_of_a_launch(ctx, oracle):
         ctx.set_option("dyn_tail_tiles", 16384)
 
 
+@pytest.mark.parametrize("mv", MFMA_VARIANTS)
 @pytest.mark.parametrize("counts_mode", [0, 1])
-def test_staged_rectangles_with_few_emitting_lanes(ctx, counts_mode):
+def test_staged_rectangles_with_few_emitting_lanes(ctx, counts_mode, mv):
     """Staged rectangles (invalid tile slots below the diagonal) x remainder split
     with pieces longer than a tile x a threshold only a handful of pairs pass:
     the combination in which an inlined record append once corrupted the sums of
@@ -915,7 +926,7 @@ def test_staged_rectangles_with_few_emitting_lanes(ctx, counts_mode):
     import torch
     from cuking_amd.dist import GpuStagedOps, staged_schedule
     from oracle import pyoracle
-    select(ctx, "tiled", 5, counts_mode)
+    select(ctx, "tiled", mv, counts_mode)
     n, m, thr, seed = 514, 17182, 0.0884, 1003
     cohort = plan_cohort(n, seed)
     kind, pa, pb = cohort_to_device(cohort, 0)
@@ -975,7 +986,7 @@ def test_closed_form_class_counts_on_the_gpu(ctx, kernel, variant):
             assert int(res["ibs1"][0]) == want["shared"] - int(res["ibs0"][0]) - int(res["ibs2"][0])
 
 
-@pytest.mark.parametrize("kernel,variant", [("tiled", 5), ("tiled", 2), ("stream", 0)])
+@pytest.mark.parametrize("kernel,variant", [("tiled", 5), ("tiled", 6), ("tiled", 2), ("stream", 0)])
 def test_wide_pair_with_4opp_beyond_2_24_on_the_gpu(ctx, kernel, variant):
     """4.6 M sites, 4 x opposing_hom > 2^24: exact sums (float32 accumulation in the
     matrix-core kernel included) and the documented left-to-right float32 kin."""
@@ -1072,7 +1083,7 @@ def test_reserved_workspace_means_no_allocation_and_no_host_wait(oracle):
         c.close()
 
 
-@pytest.mark.parametrize("variant", [5, 0])
+@pytest.mark.parametrize("variant", [5, 6, 0])
 def test_reuse_prepared_layout_and_invalidate(oracle, variant):
     """Option "reuse_prepared": a repeated call on the same (block, width, shape,
     bitset pointer) launches the pair kernel only; a host that rewrites the bitset
