@@ -151,7 +151,7 @@ int default_variant() {
     const int k = atoi(v);
     if (k >= 0 && k < kNumTiledVariants) return k;
   }
-  return kMfmaVariant;
+  return kMfmaN4Variant;
 }
 
 // The variant that runs for a bitset of this width: the matrix-core variant
@@ -220,7 +220,7 @@ PlaneGeometry make_geometry(const cuking_submatrix &sm,
 // keep 17 (see cuking_ctx::band_rows in the round-1 notes, tools/rect_probe.py).
 uint32_t band_rows_for(uint32_t pinned, const PlaneGeometry &g, const TiledVariant &v) {
   if (pinned != 0) return pinned;
-  if (v.layout != kLayoutQuad) return 17;
+  if (v.layout == kLayoutWord) return 17;
   return g.rows_padded / v.tile >= 128 ? 5 : 17;
 }
 

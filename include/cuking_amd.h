@@ -180,8 +180,11 @@ typedef enum cuking_kernel {
 } cuking_kernel;
 cuking_status cuking_ctx_set_kernel(cuking_ctx *ctx, cuking_kernel kernel);
 /* Tuning knobs of the tiled kernel: "variant" (compiled kernel shape, 0 ..
- * cuking_num_variants()-1; also env CUKING_AMD_VARIANT; the default is the
- * matrix-core variant, 0..4 are VALU AND/popcount shapes), "split_wgs"
+ * cuking_num_variants()-1; also env CUKING_AMD_VARIANT; 0..4 are VALU
+ * AND/popcount shapes, 5 and 6 the matrix-core kernels: 5 = five plane products
+ * on the reference's two bit planes, 6 = four plane products on one fp4 code per
+ * site, the default -- it serves bitsets below 2^22 sites and hands wider ones to
+ * 5, which hands bitsets from 2^24 sites on to VALU shape 2), "split_wgs"
  * (matrix-core variant: short launches cut their remainder of tiles into this
  * many equal pieces, default one per CU, 0 = never), "band_rows"
  * (tile-rows per scheduling band, 1..64, 0 = chosen by block size, the default;
@@ -226,11 +229,14 @@ const char *cuking_variant_name(int variant);
  * partial sum of num = 2 bh - 4 opp - hi - hj is an integer below 2^24, so the
  * value is the same for every association order and every FMA contraction a
  * compiler may apply to cuking.cu:291-294: bit-exact against the reference.
- * From 2^22 sites on, this library evaluates the expression left to right
- * with one float32 rounding per operation (no contraction); a reference build
- * that fuses multiply-adds may differ there in the last bit.  The matrix-core
- * variant counts in float32 and serves bitsets up to 2^24 sites; wider ones
- * take a VALU variant automatically (same records).
+ * (The default kernel evaluates num as the integer hi + hj - 2 dd + 2 q, dd =
+ * sites where both samples are defined, q = concordant - opposing homozygous
+ * sites: the same integer, so the same float, below 2^22 sites; it is not used
+ * beyond.)  From 2^22 sites on, this library evaluates the expression left to
+ * right with one float32 rounding per operation (no contraction); a reference
+ * build that fuses multiply-adds may differ there in the last bit.  The
+ * matrix-core variants count in float32 and serve bitsets up to 2^24 sites; wider
+ * ones take a VALU variant automatically (same records).
  *
  * Streams.  The compute / prepare entry points convert the bitset into a
  * kernel-internal layout held by the context.  Calls on different streams of

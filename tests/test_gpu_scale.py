@@ -8,7 +8,8 @@ threshold, i < j, sorted and unique, idempotence, identical records from an
 independent kernel (VALU popcount variant), the union of tile ranges, and
 (c) 64-bit indexing: configs[4] holds 734,000 x 6,250 u64 words, so the
 samples at the far end sit beyond element offset 2^32 of the bitset
-(cuking.cu:205-208, :514) and beyond byte offset 2^32 of the kernel layout.
+(cuking.cu:205-208, :514) and beyond byte offset 2^32 of the kernel layout
+(73.4 GB in the default kernel's one-code-per-site form, beside the 36.7 GB bitset).
 
 Times on MI355X (round 1): configs[2] 0.64 s, configs[3] geometry 8.9 s,
 configs[4] last tiles 0.6 s, whole configs[4] triangle 72 s
@@ -27,7 +28,7 @@ from cuking_amd.synth import DEFAULT_SEED, cohort_to_device, plan_cohort
 
 pytestmark = pytest.mark.gpu
 
-MFMA, VALU_T64, VALU_T128 = 5, 1, 2
+MFMA, MFMA5, VALU_T64, VALU_T128 = 6, 5, 1, 2   # default (four products), five products, VALU
 
 
 def synthesise(ctx, n, m):
@@ -106,6 +107,8 @@ def test_c2_100k_x_100k_whole_triangle(ctx, oracle):
     # other form (five sums for every pair): identical bytes
     assert ctx.run(sm, wps, bits, thr, max_results=4 << 20).tobytes() == res.tobytes()
     ctx.set_option("variant", VALU_T64)
+    assert ctx.run(sm, wps, bits, thr, max_results=4 << 20).tobytes() == res.tobytes()
+    ctx.set_option("variant", MFMA5)          # ... and the five-product matrix-core kernel
     assert ctx.run(sm, wps, bits, thr, max_results=4 << 20).tobytes() == res.tobytes()
     ctx.set_option("variant", MFMA)
     ctx.set_option("counts_mode", 1)
