@@ -262,14 +262,19 @@ def roofline_block(args, ctx, *, launch_pairs, sites, wps, thr, king_ms, prepare
                            "not measured for this workload"),
         "kernel": kernel_name, "kernel_ms": king_ms,
         "kernel_ms_source": "HIP events around every launch on its stream, this run",
-        "kernel_ms_rocprof": prof.get("rocprof_avg_ms"),
-        "kernel_ms_rocprof_source": (prof.get("rocprof_source") if prof.get("rocprof_avg_ms")
+        # (committed figure of ANOTHER run, possibly another box: the median of the
+        #  timed launches where the profile has it, else rocprofv3's average)
+        "kernel_ms_rocprof": prof.get("rocprof_median_ms") or prof.get("rocprof_avg_ms"),
+        "kernel_ms_rocprof_source": (prof.get("rocprof_source")
+                                     if (prof.get("rocprof_median_ms") or prof.get("rocprof_avg_ms"))
                                      else None),
         "launches": launches, "prepare_ms": prepare_ms,
         "sustained_clock_mhz": clock_mhz,
-        "sustained_clock_source": ("in-kernel s_memtime / s_memrealtime probe during a "
-                                   "separate pass of the same steps (cuking_clock_probe)"
-                                   if clock_mhz else None),
+        "sustained_clock_source": ("in-kernel s_memtime / s_memrealtime probe of ONE wavefront "
+                                   "on one CU during a separate pass of the same steps "
+                                   "(cuking_clock_probe): indicative only -- the chip-wide clock "
+                                   "under the kernel is effective_clock_mhz_pmc in "
+                                   "profiles/hbm_traffic.json" if clock_mhz else None),
     }
     if mfma:
         macs = MFMA_MACS_PER_PAIR_SITE[variant][form]

@@ -431,7 +431,7 @@ def test_options_round_trip(ctx):
     kernel variant is the matrix-core one."""
     fresh = cuking_amd.KingContext(0)
     try:
-        assert fresh.get_option("variant") == 5 and fresh.variant_name() == "t128_mfma_fp4"
+        assert fresh.get_option("variant") == 6 and fresh.variant_name() == "t128_mfma_fp4_n4"
         assert fresh.get_option("split_wgs") > 0 and fresh.get_option("counts_mode") == -1
         assert fresh.get_option("xcd_swizzle") == 2 and fresh.get_option("band_rows") == 0
         for key, value in (("variant", 2), ("band_rows", 9), ("counts_mode", 1), ("split_wgs", 0),
