@@ -42,7 +42,10 @@ namespace cuking {
 //     bit 2  Y   hom-ref or hom-alt        (0100 = 2.0)
 //     bit 3  A   hom-alt: the SIGN of Y    (1100 = -2.0)
 // i.e. hom-ref 0110, het 0011, hom-alt 1110, missing / padding 0000.  4 bits per
-// sample and site = twice the bytes of the quad layout.
+// sample and site = twice the bytes of the quad layout.  Behind the codes
+// (at planes + k_words * s_stride) sits a het-only copy in quad form, one uint4
+// per 128 sites and sample, hetq[q * s_stride + s], for the full form's hom_hom
+// pass (1 bit per sample and site more).
 // ---------------------------------------------------------------------------
 constexpr uint32_t kLayoutWord = 0;
 constexpr uint32_t kLayoutQuad = 1;
@@ -168,7 +171,8 @@ __host__ __device__ inline size_t plane_bytes(const PlaneGeometry &g,
                                               uint32_t layout) {
   // word layout: 16 B per 32-site word and sample; quad layout: 2 x 16 B per
   // four words and sample; nibble layout: 16 B per 32 sites and sample.
-  return (size_t)g.k_words * g.s_stride * (layout == kLayoutQuad ? 8 : 16);
+  const size_t base = (size_t)g.k_words * g.s_stride * (layout == kLayoutQuad ? 8 : 16);
+  return layout == kLayoutNibble ? base + base / 4 : base;  // + the het-only copy
 }
 
 // One compiled shape of the tiled kernel.

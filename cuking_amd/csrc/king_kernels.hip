@@ -209,6 +209,20 @@ __global__ __launch_bounds__(256) void prepare_nibbles_kernel(
     }
     planes[(uint64_t)k * geo.s_stride + s0 + s] = make_uint4(out[0], out[1], out[2], out[3]);
   }
+  // ... and the het plane once more as it is, transposed (the quad layout's
+  // plane 0), behind the codes: what the full form's hom_hom pass reads.
+  uint4 *hetq = planes + (uint64_t)geo.k_words * geo.s_stride;
+  constexpr int kQuads = kPrepWords / 2;
+#pragma unroll
+  for (int it = 0; it < kQuads * kPrepSamples / 256; ++it) {
+    const uint32_t idx = it * 256 + threadIdx.x;
+    const uint32_t s = idx % kPrepSamples, ql = idx / kPrepSamples;
+    const uint32_t q = w0 / 2 + ql;
+    if (q * 4 >= geo.k_words || s0 + s >= geo.s_stride) continue;
+    const uint64_t lo = het_lds[s][2 * ql], hi = het_lds[s][2 * ql + 1];
+    hetq[(uint64_t)q * geo.s_stride + s0 + s] =
+        make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+  }
 }
 
 // ---------------------------------------------------------------------------

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   // opp, bh, hi, hj; four products: hi / 2, hj / 2, dd, 4 q).  The full form's
   // fifth sum, hom_hom, comes from a pass of its own in front of the main loop and
   // waits for the epilogue PARKED in LDS (five products) or in 64 registers that
-  // the main loop does not touch (four products: `hh5`, as 4 hom_hom).
+  // the main loop does not touch (four products: `hh5`).
   constexpr int NQ = 4;
   constexpr bool PARKED = FULL && !N4;
   constexpr bool HH5 = FULL && N4;
@@ -483,17 +483,24 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   // lean form.  (Round 1's full form made two passes of six products over
   // 32-row blocks in the compiler's order: 10.3 ms at 10k x 100k against 7.0 ms
   // lean.)
-  if constexpr (PARKED) {
+  v16f hh5[BI][2];  // full form: hom_hom of the wavefront's pairs
+  if constexpr (FULL) {
     constexpr int D = 4;  // k-steps in flight
-    v16f hh[BI][2];
+    v16f (&hh)[BI][2] = hh5;
 #pragma unroll
     for (int bi = 0; bi < BI; ++bi)
 #pragma unroll
       for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
         for (int r = 0; r < 16; ++r) hh[bi][bj][r] = 0.f;
-    const uint4 *lane_rows = g_rows + (uint64_t)g * 2 * s_stride + wr + lr;
-    const uint4 *lane_cols = g_cols + (uint64_t)g * 2 * s_stride + wc + lr;
+    // The het plane, one uint4 per 128 sites and sample: plane 0 of the quad
+    // layout (planes interleaved: quad stride 2 rows), or the het-only copy the
+    // nibble layout carries behind its codes for this pass (quad stride 1).
+    constexpr uint32_t HS = N4 ? 1 : 2;
+    const uint4 *const h_base = N4 ? a.planes + (uint64_t)a.geo.k_words * s_stride : a.planes;
+    const uint4 *lane_rows = h_base + (uint64_t)tr * kTile + (uint64_t)g * HS * s_stride + wr + lr;
+    const uint4 *lane_cols = h_base + a.geo.col_base + (uint64_t)tc * kTile +
+                             (uint64_t)g * HS * s_stride + wc + lr;
     uint4 Ha[D][BI], Hb[D][2], Hs_a[BI], Hs_b[2];
     v8i Pa[BI], Pb[2], Qa[BI], Qb[2];
     // het words of k-step min(step, last) (the repeats are masked out below)
@@ -501,7 +508,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     {                                                                          \
       uint32_t s_ = (STEP);                                                    \
       if (s_ >= num_steps) s_ = num_steps - 1;                                 \
-      const uint64_t off_ = (uint64_t)(s_ + k_first) * 4 * s_stride;           \
+      const uint64_t off_ = (uint64_t)(s_ + k_first) * 2 * HS * s_stride;      \
       _Pragma("unroll") for (int b = 0; b < 2; ++b) {                          \
         Ha[U][b] = lane_rows[off_ + b * 32];                                   \
         Hb[U][b] = lane_cols[off_ + b * 32];                                   \
@@ -563,17 +570,21 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
 #undef CUKING_HH_FRAGS
 #undef CUKING_HH_MMA
 #undef CUKING_HH_KSTEP
-    float4 *park = reinterpret_cast<float4 *>(lds + NSTAGE * kStageU4) +
-                   (size_t)wave * (4 * 4 * 64) + lane;
+    if constexpr (PARKED) {
+      float4 *park = reinterpret_cast<float4 *>(lds + NSTAGE * kStageU4) +
+                     (size_t)wave * (4 * 4 * 64) + lane;
 #pragma unroll
-    for (int bi = 0; bi < BI; ++bi)
+      for (int bi = 0; bi < BI; ++bi)
 #pragma unroll
-      for (int bj = 0; bj < 2; ++bj)
+        for (int bj = 0; bj < 2; ++bj)
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4)
-          park[((bi * 2 + bj) * 4 + r4) * 64] =
-              make_float4(hh[bi][bj][4 * r4], hh[bi][bj][4 * r4 + 1], hh[bi][bj][4 * r4 + 2],
-                          hh[bi][bj][4 * r4 + 3]);
+          for (int r4 = 0; r4 < 4; ++r4)
+            park[((bi * 2 + bj) * 4 + r4) * 64] =
+                make_float4(hh[bi][bj][4 * r4], hh[bi][bj][4 * r4 + 1], hh[bi][bj][4 * r4 + 2],
+                            hh[bi][bj][4 * r4 + 3]);
+    }
+    // (four-product form: the 64 registers stay where they are -- its main loop
+    //  needs 256 accumulators + ~100, they fit beside)
     // (the prefetches beyond the end are in registers nobody reads; the
     //  compiler's own wait counts cover them before the main loop's hand-counted
     //  LDS-DMA starts: force that here)
@@ -581,7 +592,6 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   }
 
   v16f acc[BI][2][NQ];
-  v16f hh5[BI][2];  // (four products, full form)
   constexpr uint32_t half_rows = 0;
   auto zero_acc = [&]() {
 #pragma unroll
@@ -849,7 +859,13 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     // so four MFMAs per block pair and 64 sites instead of five give the
     // threshold decision (the minimum: {numerator, hi, hj} is not in the span of
     // three rank-1 products), and one more sum -- hom_hom, recounted for the few
-    // emitted pairs (lean) or a fifth product Y_i.Y_j (full) -- gives bh and opp.
+    // emitted pairs (lean) or from the pass in front of this loop (full form: the
+    // same het-plane pass as the five-product kernel's, reading a het-only copy
+    // behind the codes; a fifth product Y_i.Y_j inside this loop would need 320
+    // accumulator registers, which the compiler then shuffles between the two
+    // halves of the register file around every MFMA, and a pass of its own over
+    // the staged codes moves all the bytes again for a quarter of the MFMAs:
+    // 3.2 ms of 8.8 at 10k x 100k) -- gives bh and opp.
     // T needs a sign: the nibble layout (king_common.h) stores one fp4 code per
     // site, H at bit 0 (0.5), D at bit 1 (1.0), Y at bit 2 (2.0), hom-alt in the
     // SIGN bit, so that every fragment is ONE v_and_b32 of a stored dword with a
@@ -869,7 +885,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     constexpr int kStageN4 = 2 * 2 * 4 * kSliceU4;   // uint4 per stage (32 KiB)
     uint32_t mT;
     asm volatile("s_mov_b32 %0, 0xcccccccc" : "=s"(mT));
-    const uint32_t mH = m1, mD = m2, mY = m4;
+    const uint32_t mH = m1, mD = m2;
     // DMA: wavefront (side, k-group) fetches that quarter of a stage: 4 slices x
     // 2 halves of 64 samples, 1 KiB each.  Slice c of k-step s is group
     // 8 s + 4 kg + c of the layout.
@@ -1024,59 +1040,21 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       /* q = T_i.T_j */                                                        \
       N4_LAST_GROUP(3, 2, 2, NXT)                                              \
     }
-// One slice of the full form's hom_hom pass: 4 MFMAs Y_i.Y_j on the fragments the
-// slice before built, the two requests, the reads of the slice after next and
-// the Y fragments of the next slice.
-#define N4_YSLICE(CUR, NXT, RBUF, RSLICE, SYNC, C)                             \
-    {                                                                          \
-      _Pragma("unroll") for (int r = 0; r < 2; ++r) {                          \
-        n4_issue(pa, C, r);                                                    \
-        hh5[0][r] = mma<1>(Fa[3][0], Fb[3][r], hh5[0][r]);                     \
-        __builtin_amdgcn_sched_barrier(0);                                     \
-      }                                                                        \
-      _Pragma("unroll") for (int r = 0; r < 2; ++r)                            \
-        hh5[1][r] = mma<1>(Fa[3][1], Fb[3][r], hh5[1][r]);                     \
-      __builtin_amdgcn_sched_barrier(0);                                       \
-      if (SYNC) n4_sync();                                                     \
-      N4_READ(CUR, RBUF, RSLICE)                                               \
-      N4_PIN_RAW_A(NXT) N4_PIN_RAW_B(NXT)                                      \
-      N4_BUILD_A(3, NXT, mY) N4_BUILD_B(3, NXT, mY)                            \
-      N4_PIN_A(3) N4_PIN_B(3)                                                  \
-      __builtin_amdgcn_sched_barrier(0);                                       \
-    }
+    zero_acc();
     if constexpr (HH5) {
-      // Full form: hom_hom = Y_i.Y_j in a pass of its own over the same stages (a
-      // fifth product inside the main loop would need 320 accumulator registers:
-      // the compiler then shuffles 64 of them between the two halves of the
-      // register file around every MFMA).  Its 64 registers stay where they are
-      // while the main loop runs: that loop needs 256 + ~100.
+      // 320 accumulator-like registers for a 256-entry accumulator file: say
+      // which 64 live in the other half (left to itself the compiler moves some
+      // of each through v_accvgpr copies around every MFMA of the split
+      // instantiation's main loop: 368 copies per k-step).
 #pragma unroll
       for (int bi = 0; bi < BI; ++bi)
 #pragma unroll
-        for (int bj = 0; bj < 2; ++bj)
+        for (int bj = 0; bj < 2; ++bj) {
+          asm volatile("" : "+v"(hh5[bi][bj]));
 #pragma unroll
-          for (int r = 0; r < 16; ++r) hh5[bi][bj][r] = 0.f;
-      n4_prologue();
-      N4_READ(0, 0, 0)
-      N4_READ(1, 0, 1)
-      N4_BUILD_A(3, 0, mY) N4_BUILD_B(3, 0, mY)
-      uint32_t buf = 0;
-      N4Addr pa = n4_addr(NSTAGE - 1, NSTAGE - 1);
-      for (uint32_t step = 0; step < num_steps; ++step) {
-        const uint32_t nbuf = buf == NSTAGE - 1 ? 0 : buf + 1;
-        N4_YSLICE(0, 1, buf, 2, false, 0)
-        N4_YSLICE(1, 0, buf, 3, false, 1)
-        N4_YSLICE(0, 1, nbuf, 0, true, 2)
-        N4_YSLICE(1, 0, nbuf, 1, false, 3)
-        pa = n4_addr(step + NSTAGE, buf);
-        buf = nbuf;
-      }
-      // the clamped repeats have landed and nobody reads the stages any more,
-      // before the main loop's prologue overwrites them
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-      __syncthreads();
+          for (int q = 0; q < NQ; ++q) asm volatile("" : "+a"(acc[bi][bj][q]));
+        }
     }
-    zero_acc();
     n4_prologue();
     N4_READ(0, 0, 0)
     N4_READ(1, 0, 1)
@@ -1110,7 +1088,6 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
 #undef N4_READ_GROUP
 #undef N4_LAST_GROUP
 #undef N4_SLICE
-#undef N4_YSLICE
   }
   // The clamped repeats of the last stage must have landed before the
   // workgroup's LDS goes away.
@@ -1267,7 +1244,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   const EmitCtx emit_ctx = make_emit_ctx(a);
   // The five sums of pair (bi, bj, r) as integers.  Five products: they are the
   // accumulators (hom_hom parked, `parked`).  Four products: hi / 2, hj / 2, dd,
-  // 4 q (and 4 hom_hom in hh5) are, and bh = hi + hj - dd + hom_hom,
+  // 4 q (and hom_hom in hh5) are, and bh = hi + hj - dd + hom_hom,
   // opp = (hom_hom - q) / 2.
   auto pair_sums = [&](int bi, int bj, int r, float parked, uint32_t *het_i, uint32_t *het_j,
                        uint32_t *both_het, uint32_t *opp, uint32_t *hom_hom) {
@@ -1276,7 +1253,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       *het_j = (uint32_t)(2.f * acc[bi][bj][1][r]);
       const uint32_t dd = (uint32_t)acc[bi][bj][2][r];
       const int32_t q = (int32_t)(0.25f * acc[bi][bj][3][r]);
-      const uint32_t hh = HH5 ? (uint32_t)(0.25f * hh5[bi][bj][r]) : 0u;  // (full form only)
+      const uint32_t hh = HH5 ? (uint32_t)hh5[bi][bj][r] : 0u;  // (full form only)
       *hom_hom = hh;
       *both_het = *het_i + *het_j - dd + hh;
       *opp = (uint32_t)((int32_t)hh - q) >> 1;
