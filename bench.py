@@ -139,6 +139,8 @@ def parse_args():
                     help="skip the planted-relatives check (timing-only tuning kernels)")
     ap.add_argument("--no-clock-pass", action="store_true",
                     help="skip the sustained-clock pass after the timed region")
+    ap.add_argument("--max-launch-blocks", type=int, default=-1,
+                    help="experiment: cap the workgroups per launch (library test hook)")
     ap.add_argument("--convert-every-step", action="store_true",
                     help="convert the bitset into the kernel-internal layout in every step "
                          "(default: once per cohort, reused -- the bitset does not change)")
@@ -707,6 +709,8 @@ def main():
         ctx.set_option("xcd_swizzle", args.xcd_swizzle)
     if args.split_wgs >= 0:
         ctx.set_option("split_wgs", args.split_wgs)
+    if args.max_launch_blocks >= 0:
+        ctx.set_option("max_launch_blocks", args.max_launch_blocks)
     # The cohort is not rewritten between steps: the kernel-internal layout is
     # converted by the first call and reused by the others (--convert-every-step
     # restores one conversion per step; it is reported either way).

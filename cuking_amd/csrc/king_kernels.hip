@@ -155,41 +155,65 @@ __device__ __forceinline__ uint32_t spread8(uint32_t b) {
   return x;
 }
 
+// One workgroup: 64 plane-samples x kNibWords source words of each plane, read
+// 16 bytes per lane in runs of 256 contiguous bytes per sample and plane (the
+// rows of the reference layout are words_per_sample x 8 bytes apart, so longer
+// runs mean fewer DRAM pages per byte), transposed through LDS, written 1 KiB
+// per k-row (64 consecutive samples).
+constexpr int kNibWords = 32;
+
 __global__ __launch_bounds__(256) void prepare_nibbles_kernel(
     const uint64_t *__restrict__ bits, uint32_t words_per_sample,
     PlaneGeometry geo, uint4 *__restrict__ planes, uint32_t s_tile_begin) {
-  __shared__ uint64_t het_lds[kPrepSamples][kPrepWords + 1];
-  __shared__ uint64_t hom_lds[kPrepSamples][kPrepWords + 1];
+  __shared__ uint64_t het_lds[kPrepSamples][kNibWords + 1];
+  __shared__ uint64_t hom_lds[kPrepSamples][kNibWords + 1];
 
   const uint32_t plane_words = words_per_sample / 2;
   const uint32_t s0 = (s_tile_begin + blockIdx.x) * kPrepSamples;
-  const uint32_t w0 = blockIdx.y * kPrepWords;
+  const uint32_t w0 = blockIdx.y * kNibWords;
+  // (plane_words even <=> a sample's planes start 16-byte aligned whenever the
+  //  bitset does; otherwise fall back to 8-byte loads)
+  const bool wide = (plane_words & 1) == 0 && (words_per_sample & 1) == 0 &&
+                    (reinterpret_cast<uintptr_t>(bits) & 15) == 0;
 
 #pragma unroll
-  for (int it = 0; it < kPrepSamples * kPrepWords / 256; ++it) {
+  for (int it = 0; it < kPrepSamples * kNibWords / 2 / 256; ++it) {
     const uint32_t idx = it * 256 + threadIdx.x;
-    const uint32_t s = idx / kPrepWords, w = idx % kPrepWords;
-    const uint32_t ps = s0 + s;
-    uint32_t src = 0xFFFFFFFFu;
+    const uint32_t s = idx / (kNibWords / 2), w = (idx % (kNibWords / 2)) * 2;
+    const uint32_t ps = s0 + s;  // plane sample index
+    uint32_t src = 0xFFFFFFFFu;  // which stored sample of the reference bitset, if any
     if (geo.diag || ps < geo.rows_padded) {
       if (ps < geo.num_rows) src = ps;
     } else {
       const uint32_t c = ps - geo.col_base;
       if (c < geo.num_cols) src = geo.num_rows + c;
     }
-    uint64_t het = ~0ull, hom = ~0ull;  // missing
+    uint64_t het[2] = {~0ull, ~0ull}, hom[2] = {~0ull, ~0ull};  // missing
     if (src != 0xFFFFFFFFu && w0 + w < plane_words) {
       const uint64_t *p = bits + (uint64_t)src * words_per_sample + (w0 + w);
-      het = p[0];
-      hom = p[plane_words];
+      if (wide && w0 + w + 1 < plane_words) {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(p);
+        const ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(p + plane_words);
+        het[0] = a.x; het[1] = a.y;
+        hom[0] = b.x; hom[1] = b.y;
+      } else {
+        het[0] = p[0];
+        hom[0] = p[plane_words];
+        if (w0 + w + 1 < plane_words) {
+          het[1] = p[1];
+          hom[1] = p[plane_words + 1];
+        }
+      }
     }
-    het_lds[s][w] = het;
-    hom_lds[s][w] = hom;
+    het_lds[s][w] = het[0];
+    het_lds[s][w + 1] = het[1];
+    hom_lds[s][w] = hom[0];
+    hom_lds[s][w + 1] = hom[1];
   }
   __syncthreads();
 
 #pragma unroll
-  for (int it = 0; it < kPrepSamples * kPrepWords * 2 / 256; ++it) {
+  for (int it = 0; it < kPrepSamples * kNibWords * 2 / 256; ++it) {
     const uint32_t idx = it * 256 + threadIdx.x;
     const uint32_t krow = idx / kPrepSamples, s = idx % kPrepSamples;
     const uint32_t k = w0 * 2 + krow;
@@ -212,7 +236,7 @@ __global__ __launch_bounds__(256) void prepare_nibbles_kernel(
   // ... and the het plane once more as it is, transposed (the quad layout's
   // plane 0), behind the codes: what the full form's hom_hom pass reads.
   uint4 *hetq = planes + (uint64_t)geo.k_words * geo.s_stride;
-  constexpr int kQuads = kPrepWords / 2;
+  constexpr int kQuads = kNibWords / 2;
 #pragma unroll
   for (int it = 0; it < kQuads * kPrepSamples / 256; ++it) {
     const uint32_t idx = it * 256 + threadIdx.x;
@@ -741,8 +765,9 @@ hipError_t launch_prepare_planes(uint32_t layout, const uint64_t *d_bit_sets,
   const uint32_t all = (geo.s_stride + kPrepSamples - 1) / kPrepSamples;
   if (s_tile_end > all) s_tile_end = all;
   if (s_tile_begin >= s_tile_end) return hipSuccess;
+  const uint32_t block_words = layout == kLayoutNibble ? kNibWords : kPrepWords;
   const dim3 grid(s_tile_end - s_tile_begin,
-                  (geo.k_words + 2 * kPrepWords - 1) / (2 * kPrepWords));
+                  (geo.k_words + 2 * block_words - 1) / (2 * block_words));
   if (grid.y == 0) return hipSuccess;
   if (layout == kLayoutQuad)
     prepare_quads_kernel<<<grid, dim3(256), 0, stream>>>(

@@ -34,7 +34,7 @@ if (src / "trace_steps.txt").exists():
 
 
 def short_name(name):
-    name = re.sub(r"^void cuking::\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^(void )?cuking::\(anonymous namespace\)::", "", name)
     return re.sub(r"\(.*\)$", "", name)
 
 
@@ -98,7 +98,9 @@ entry = {
     "frac_same_box": bench["roofline"].get("frac"),
     "mfma_busy_fraction": (counters.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024) /
                           (counters["GRBM_GUI_ACTIVE"] / 8) if "GRBM_GUI_ACTIVE" in counters else None,
-    "effective_clock_mhz_pmc": counters["GRBM_GUI_ACTIVE"] / 8 / (ref_ms * 1e-3) / 1e6
+    # (counters are per LAUNCH, durations per pass)
+    "effective_clock_mhz_pmc": counters["GRBM_GUI_ACTIVE"] * pair.get("launches_per_pass", 1) / 8 /
+                               (ref_ms * 1e-3) / 1e6
     if "GRBM_GUI_ACTIVE" in counters and ref_ms else None,
     "effective_clock_note": "GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / the kernel's median "
                             "duration: the chip-wide clock under this kernel (MI355X_MICROARCH.md, "
@@ -113,7 +115,8 @@ wps = bench["roofline"].get("hbm", {}).get("algorithmic_bytes_per_pair", 0) // 1
 for name, d in durations.items():
     if name.startswith("prepare_"):
         read = cfg["samples"] * wps * 8
-        write = read * (2 if ("nibbles" in name or "planes" in name) else 1)
+        # (nibble layout: 4 bits per site + the het-only copy; word layout 2 x)
+        write = read * 9 // 4 if "nibbles" in name else read * (2 if "planes" in name else 1)
         gbps = (read + write) / (d["median_ms"] * 1e-3) / 1e9
         table[f"{key}:{name}"] = {
             "round": rnd, "kernel": name, "bound": "hbm", "median_ms": d["median_ms"],
