@@ -292,9 +292,12 @@ void PrintSchedule(const Flags &flags, const cuking_submatrix &sm) {
   for (size_t c = 0; c < chunks.size(); ++c)
     std::cout << (c ? ", " : "") << "[" << chunks[c].begin << ", " << chunks[c].end << "]";
   std::cout << "], \"staged\": [";
+  const cuking_host::RowDeal deal = cuking_host::MakeRowDeal(
+      world, staged ? flags.rank_weight_values : std::vector<double>());
   for (uint32_t r = 0; r < world; ++r) {
     std::cout << (r ? ", " : "") << "[";
-    const auto steps = cuking_host::StagedSchedule(stored, tile, world, r, flags.bcast_chunks);
+    const auto steps =
+        cuking_host::StagedSchedule(stored, tile, world, r, flags.bcast_chunks, &deal);
     for (size_t k = 0; k < steps.size(); ++k) {
       const auto &s = steps[k];
       std::cout << (k ? ", " : "") << "{\"chunk\": [" << s.chunk.begin << ", " << s.chunk.end
@@ -303,8 +306,19 @@ void PrintSchedule(const Flags &flags, const cuking_submatrix &sm) {
         std::cout << "[" << s.row_begin << ", " << s.row_end << ", " << s.row_step << "]";
       else
         std::cout << "null";
-      std::cout << "}";
+      std::cout << ", \"rects\": [";
+      for (size_t q = 0; q < s.rects.size(); ++q)
+        std::cout << (q ? ", " : "") << "[" << s.rects[q].row_begin << ", " << s.rects[q].row_end
+                  << ", " << s.rects[q].row_step << "]";
+      std::cout << "]}";
     }
+    std::cout << "]";
+  }
+  std::cout << "], \"row_deal_period\": " << deal.period << ", \"row_deal\": [";
+  for (uint32_t r = 0; r < world; ++r) {
+    std::cout << (r ? ", " : "") << "[";
+    for (size_t q = 0; q < deal.offsets[r].size(); ++q)
+      std::cout << (q ? ", " : "") << deal.offsets[r][q];
     std::cout << "]";
   }
   std::cout << "]}" << std::endl;

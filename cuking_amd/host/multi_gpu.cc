@@ -226,9 +226,17 @@ void RankMain(Shared *sh, PhaseBarrier *barrier, int rank) {
 
   // ---- exchange step 1 + compute ---------------------------------------------
   const double t0 = Now();
+  // (staged schedule: --rank_weights deals the tile rows in proportion; the
+  //  calibration launch belongs to the simple schedule)
+  const RowDeal deal = MakeRowDeal(world, sh->staged ? in.rank_weights : std::vector<double>());
   const std::vector<StagedStep> steps =
-      StagedSchedule(stored, sh->tile, world, rank, in.chunks);
-  for (const StagedStep &s : steps) {
+      StagedSchedule(stored, sh->tile, world, rank, in.chunks, &deal);
+  // Exchange first: every upload and broadcast is enqueued before any compute
+  // call is made, so that nothing on the host (a calibration wait, a slow launch)
+  // delays the chunks still to come; chunk c's kernels wait for its event.
+  std::vector<hipEvent_t> arrived(steps.size(), nullptr);
+  for (size_t k = 0; k < steps.size(); ++k) {
+    const StagedStep &s = steps[k];
     const size_t off = (size_t)s.chunk.begin * wps;                       // words
     const size_t bytes = (size_t)(s.chunk.end - s.chunk.begin) * wps * 8;
     if (rank == 0 && in.host_bits != nullptr) {
@@ -241,19 +249,23 @@ void RankMain(Shared *sh, PhaseBarrier *barrier, int rank) {
       if (ok && up) RANK_HIP(hipStreamWaitEvent(st.comm, up, 0));
     }
     RANK_COLL(coll->Broadcast(rank, st.d_bits + off, bytes, 0, st.comm));
-    hipEvent_t arrived = NewEvent(st);
-    if (ok && arrived) RANK_HIP(hipEventRecord(arrived, st.comm));
-    if (ok && arrived) RANK_HIP(hipStreamWaitEvent(st.compute, arrived, 0));
+    arrived[k] = NewEvent(st);
+    if (ok && arrived[k]) RANK_HIP(hipEventRecord(arrived[k], st.comm));
+  }
+  for (size_t k = 0; k < steps.size(); ++k) {
+    const StagedStep &s = steps[k];
+    if (ok && arrived[k]) RANK_HIP(hipStreamWaitEvent(st.compute, arrived[k], 0));
     if (sh->staged && s.has_rect && ok) {
       RANK_ABI(cuking_prepare_samples(st.ctx, &in.sm, wps, st.d_bits,
                                       in.sm.i_begin + s.chunk.begin,
                                       in.sm.i_begin + s.chunk.end, st.compute));
-      if (ok)
-        RANK_ABI(cuking_compute_king_rect(
-            st.ctx, &in.sm, wps, st.d_bits, in.sm.i_begin + s.row_begin,
-            in.sm.i_begin + s.row_end, s.row_step, in.sm.i_begin + s.chunk.begin,
-            in.sm.i_begin + s.chunk.end, in.kin_threshold, in.max_results, st.d_results,
-            st.d_counters, st.d_counters + 1, st.compute));
+      for (const RowStride &r : s.rects)
+        if (ok)
+          RANK_ABI(cuking_compute_king_rect(
+              st.ctx, &in.sm, wps, st.d_bits, in.sm.i_begin + r.row_begin,
+              in.sm.i_begin + r.row_end, r.row_step, in.sm.i_begin + s.chunk.begin,
+              in.sm.i_begin + s.chunk.end, in.kin_threshold, in.max_results, st.d_results,
+              st.d_counters, st.d_counters + 1, st.compute));
     }
   }
   TileRange mine = {0, 0};

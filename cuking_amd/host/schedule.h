@@ -101,24 +101,108 @@ inline std::vector<SampleChunk> ChunkRanges(uint32_t num_samples, uint32_t tile,
   return out;
 }
 
+// Which tile rows a rank owns in the staged schedule: row r belongs to the rank
+// that owns position r mod period of the deal.  Unweighted: period = world,
+// position p -> rank p (round-robin).  Weighted (the GPUs of a node differ by
+// several percent): period = 16 x world positions, rank r gets a share of them
+// in proportion to its weight (largest remainders), spread evenly over the
+// period by smooth weighted round-robin -- evenly, because the rows of a chunk's
+// own triangle differ in length and a rank with the first rows of every period
+// would get more of it.
+struct RowDeal {
+  uint32_t period = 1;
+  std::vector<std::vector<uint32_t>> offsets;  // per rank: its positions in [0, period)
+};
+
+inline RowDeal MakeRowDeal(uint32_t world, const std::vector<double> &weights) {
+  RowDeal d;
+  d.offsets.assign(world, {});
+  if (weights.size() != world) {
+    d.period = world;
+    for (uint32_t r = 0; r < world; ++r) d.offsets[r].push_back(r);
+    return d;
+  }
+  d.period = 16 * world;
+  double total = 0;
+  for (double w : weights) total += w;
+  // positions per rank: floor of the exact share, the rest by largest remainder
+  std::vector<uint32_t> n(world);
+  std::vector<std::pair<double, uint32_t>> rem;
+  uint32_t given = 0;
+  for (uint32_t r = 0; r < world; ++r) {
+    const double exact = d.period * weights[r] / total;
+    n[r] = (uint32_t)exact;
+    if (n[r] == 0) n[r] = 1;  // every rank takes part
+    given += n[r];
+    rem.push_back({exact - std::floor(exact), r});
+  }
+  for (uint32_t k = 0; given < d.period; ++k) {
+    uint32_t best = 0;
+    for (uint32_t r = 1; r < world; ++r)
+      if (rem[r].first > rem[best].first) best = r;
+    ++n[best];
+    rem[best].first = -1;
+    ++given;
+    if (k > 4 * world) break;
+  }
+  while (given > d.period) {  // (the "at least one" rule overshot: take from the largest)
+    uint32_t big = 0;
+    for (uint32_t r = 1; r < world; ++r)
+      if (n[r] > n[big]) big = r;
+    --n[big];
+    --given;
+  }
+  // smooth weighted round-robin: every rank's positions evenly spread
+  std::vector<int64_t> cur(world, 0);
+  for (uint32_t p = 0; p < d.period; ++p) {
+    uint32_t pick = 0;
+    for (uint32_t r = 0; r < world; ++r) {
+      cur[r] += n[r];
+      if (cur[r] > cur[pick]) pick = r;
+    }
+    cur[pick] -= d.period;
+    d.offsets[pick].push_back(p);
+  }
+  return d;
+}
+
+struct RowStride {
+  uint32_t row_begin, row_end, row_step;  // rows row_begin, +row_step, ... < row_end (samples)
+};
+
 struct StagedStep {
   SampleChunk chunk;  // arrives in this step (= the rectangle's columns)
   bool has_rect;      // false: none of the rank's rows lie below the chunk end
-  uint32_t row_begin, row_end, row_step;  // rows row_begin, +row_step, ... < row_end
+  uint32_t row_begin, row_end, row_step;  // the first (unweighted: the only) row set
+  std::vector<RowStride> rects;           // every row set of the rank for this chunk
 };
 
 inline std::vector<StagedStep> StagedSchedule(uint32_t num_samples, uint32_t tile,
                                               uint32_t world, uint32_t rank,
-                                              uint32_t num_chunks) {
+                                              uint32_t num_chunks,
+                                              const RowDeal *deal = nullptr) {
+  RowDeal plain;
+  if (deal == nullptr) {
+    plain = MakeRowDeal(world, {});
+    deal = &plain;
+  }
   std::vector<StagedStep> out;
-  const uint64_t first_row = (uint64_t)rank * tile;
   for (const SampleChunk &c : ChunkRanges(num_samples, tile, num_chunks)) {
     StagedStep s;
     s.chunk = c;
-    s.has_rect = first_row < c.end;
-    s.row_begin = s.has_rect ? (uint32_t)first_row : 0;
-    s.row_end = s.has_rect ? c.end : 0;
-    s.row_step = world * tile;
+    s.has_rect = false;
+    s.row_begin = s.row_end = 0;
+    s.row_step = deal->period * tile;
+    for (uint32_t off : deal->offsets[rank]) {
+      const uint64_t first_row = (uint64_t)off * tile;
+      if (first_row >= c.end) continue;
+      s.rects.push_back({(uint32_t)first_row, c.end, deal->period * tile});
+    }
+    if (!s.rects.empty()) {
+      s.has_rect = true;
+      s.row_begin = s.rects[0].row_begin;
+      s.row_end = s.rects[0].row_end;
+    }
     out.push_back(s);
   }
   return out;

@@ -217,6 +217,45 @@ def test_weighted_tile_ranges_and_calibration_plan(tmp_path):
         assert p.returncode == 1 and needle in p.stderr, (bad, p.stderr)
 
 
+def test_weighted_row_deal_of_the_staged_schedule(tmp_path):
+    """`--rank_weights` in the staged schedule: tile rows dealt in proportion to
+    the weights, every row to exactly one rank, each rank's rows spread evenly
+    over the deal's period (host/schedule.h MakeRowDeal)."""
+    d = tmp_path / "in"
+    d.mkdir()
+    n, world = 40_000, 4
+    (d / "metadata.json").write_text(json.dumps(
+        {"num_sites": 64, "samples": [f"s{i}" for i in range(n)]}))
+    weights = [1.0, 1.10, 0.95, 1.02]
+    p = run_cli("--input_uri", d, "--output_uri", tmp_path / "o", "--print_schedule",
+                f"--num_gpus={world}", "--multi_gpu_mode=staged", "--bcast_chunks=5",
+                "--rank_weights=" + ",".join(map(str, weights)), check=True)
+    got = json.loads(p.stdout.strip().splitlines()[-1])
+    tile, period = got["tile"], got["row_deal_period"]
+    assert got["mode"] == "staged" and period == 16 * world
+    deal = got["row_deal"]
+    assert sorted(x for r in deal for x in r) == list(range(period))      # a partition
+    share = [len(r) / period for r in deal]
+    for s_, w in zip(share, weights):
+        assert abs(s_ - w / sum(weights)) <= 1.0 / period
+    assert share[1] > share[0] > share[2]
+    for r in deal:                                                       # evenly spread
+        gaps = np.diff(sorted(r) + [sorted(r)[0] + period])
+        assert gaps.max() <= -(-period // len(r)) + 1, r          # no long stretch without the rank
+    # every (tile row, chunk) rectangle row belongs to exactly one rank
+    tile_rows = (n + tile - 1) // tile
+    for k, (c0, c1) in enumerate(got["chunks"]):
+        owners = np.zeros(tile_rows, dtype=np.int32)
+        for r in range(world):
+            step = got["staged"][r][k]
+            assert tuple(step["chunk"]) == (c0, c1)
+            for b, e, st in step["rects"]:
+                assert e == c1 and st == period * tile and b % tile == 0
+                owners[np.arange(b // tile, (e + tile - 1) // tile, st // tile)] += 1
+        below = (c1 + tile - 1) // tile
+        assert np.all(owners[:below] == 1) and np.all(owners[below:] == 0)
+
+
 def test_host_threads_under_tsan(tmp_path, oracle):
     """ThreadSanitizer over the threaded host code: the reader pool (ParallelFor,
     one task per row group) decoding on 8 threads while cuking_pack_host's relaxed
@@ -605,6 +644,7 @@ def test_rccl_path_shards_overflow_and_bad_gpu_count(c0, oracle):
     ["--multi_gpu_mode=simple", "--calibration_tiles=2"],
     ["--multi_gpu_mode=simple", "--rank_weights=1,3,2"],
     ["--multi_gpu_mode=staged", "--pack=device", "--bcast_chunks=5"],
+    ["--multi_gpu_mode=staged", "--rank_weights=1,3,2", "--bcast_chunks=2"],
     ["--kernel=stream"],
 ])
 def test_three_ranks_on_one_gpu_through_the_loopback(c0, oracle, extra):
