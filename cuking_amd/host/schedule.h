@@ -16,6 +16,7 @@
 #ifndef CUKING_AMD_HOST_SCHEDULE_H_
 #define CUKING_AMD_HOST_SCHEDULE_H_
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <vector>
@@ -106,7 +107,7 @@ inline std::vector<SampleChunk> ChunkRanges(uint32_t num_samples, uint32_t tile,
 // position p -> rank p (round-robin).  Weighted (the GPUs of a node differ by
 // several percent): period = 16 x world positions, rank r gets a share of them
 // in proportion to its weight (largest remainders), spread evenly over the
-// period by smooth weighted round-robin -- evenly, because the rows of a chunk's
+// period -- evenly, because the rows of a chunk's
 // own triangle differ in length and a rank with the first rows of every period
 // would get more of it.
 struct RowDeal {
@@ -152,17 +153,17 @@ inline RowDeal MakeRowDeal(uint32_t world, const std::vector<double> &weights) {
     --n[big];
     --given;
   }
-  // smooth weighted round-robin: every rank's positions evenly spread
-  std::vector<int64_t> cur(world, 0);
-  for (uint32_t p = 0; p < d.period; ++p) {
-    uint32_t pick = 0;
-    for (uint32_t r = 0; r < world; ++r) {
-      cur[r] += n[r];
-      if (cur[r] > cur[pick]) pick = r;
-    }
-    cur[pick] -= d.period;
-    d.offsets[pick].push_back(p);
-  }
+  // every rank's positions evenly spread: its j-th of n sits nearest to
+  // (j + 1/2) x period / n; positions are handed out in the order of those targets
+  std::vector<std::pair<double, uint32_t>> targets;
+  for (uint32_t r = 0; r < world; ++r)
+    for (uint32_t j = 0; j < n[r]; ++j)
+      targets.push_back({(j + 0.5) * d.period / n[r], r});
+  std::stable_sort(targets.begin(), targets.end(),
+                   [](const std::pair<double, uint32_t> &a, const std::pair<double, uint32_t> &b) {
+                     return a.first < b.first;
+                   });
+  for (uint32_t p = 0; p < d.period; ++p) d.offsets[targets[p].second].push_back(p);
   return d;
 }
 
