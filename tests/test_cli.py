@@ -723,6 +723,53 @@ def test_loopback_ranks_overflow_failures_and_shards(c0, oracle):
 
 
 @pytest.mark.gpu
+def test_hundred_million_triples_through_both_packs(tmp_path_factory):
+    """A 1e8-genotype input (2000 samples x 50,000 sites, 8 zstd files of several
+    row groups) through the host pack and the pipelined device pack: same output
+    file, the decode handed out per row group (8 files, 16 reader threads), and
+    the device pack not slower than the host pack beyond the noise of a shared
+    box (profiles/r02_pack_pipeline.txt: equal at this size, +37 % at 1e9)."""
+    import importlib.util
+    from concurrent.futures import ProcessPoolExecutor
+    spec = importlib.util.spec_from_file_location(
+        "cli_timing", Path(__file__).resolve().parent.parent / "tools" / "cli_timing.py")
+    cli_timing = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli_timing)
+    d = tmp_path_factory.mktemp("pack1e8")
+    n, m, files = 2000, 50_000, 8
+    (d / "in").mkdir()
+    (d / "in" / "metadata.json").write_text(json.dumps(
+        {"num_sites": m, "samples": [f"S{k:07d}" for k in range(n)]}))
+    bounds = np.linspace(0, m, files + 1).astype(int)
+    jobs = [(str(d / "in"), f, int(bounds[f]), int(bounds[f + 1]), n, 1, 2_000_000)
+            for f in range(files)]
+    with ProcessPoolExecutor(8) as ex:
+        triples = sum(ex.map(cli_timing.write_part, jobs))
+    assert 0.98e8 < triples < 1.0e8
+    best, outputs = {}, {}
+    for rep in range(2):
+        for pack in ("host", "device"):
+            p = run_cli("--input_uri", d / "in", "--output_uri", d / f"out_{pack}", f"--pack={pack}",
+                        "--num_reader_threads=16", "--kin_threshold=0.05", check=True)
+            s_ = json.loads(p.stdout.strip().splitlines()[-1])
+            assert s_["triples"] == triples and s_["pack"] == pack
+            assert s_["decode_tasks"] > files            # row groups, not files
+            best[pack] = min(best.get(pack, 1e9), s_["read_pack_seconds"])
+            outputs[pack] = (d / f"out_{pack}" / "part-00000.snappy.parquet").read_bytes()
+    assert outputs["host"] == outputs["device"] and len(outputs["host"]) > 0
+    print(f"1e8 triples: host pack {best['host']:.3f} s, device pack {best['device']:.3f} s")
+    assert best["device"] <= 1.3 * best["host"], best
+    # --pack=auto takes the device pack at 16 reader threads, the host pack at 48
+    p = run_cli("--input_uri", d / "in", "--output_uri", d / "out_auto", "--num_reader_threads=16",
+                "--kin_threshold=0.05", check=True)
+    assert json.loads(p.stdout.strip().splitlines()[-1])["pack"] == "device"
+    p = run_cli("--input_uri", d / "in", "--output_uri", d / "out_auto48",
+                "--num_reader_threads=48", "--kin_threshold=0.05", check=True)
+    assert json.loads(p.stdout.strip().splitlines()[-1])["pack"] == "host"
+    assert (d / "out_auto48" / "part-00000.snappy.parquet").read_bytes() == outputs["host"]
+
+
+@pytest.mark.gpu
 def test_cli_result_overflow(c0):
     p = run_cli("--input_uri", c0["dir"] / "in", "--output_uri", c0["dir"] / "out_ovf",
                 "--kin_threshold=-10", "--max_results=1000")

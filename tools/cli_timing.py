@@ -27,7 +27,8 @@ sys.path.insert(0, str(ROOT))
 
 
 def write_part(args):
-    out, f, lo, hi, n, seed = args
+    out, f, lo, hi, n, seed = args[:6]
+    row_group_size = args[6] if len(args) > 6 else None
     import pyarrow as pa
     import pyarrow.parquet as pq
     rng = np.random.default_rng([seed, f])
@@ -40,7 +41,7 @@ def write_part(args):
     table = pa.table({"row_idx": (row + lo).astype(np.int64), "col_idx": col.astype(np.int64),
                       "n_alt_alleles": block[row, col].astype(np.int32)})
     pq.write_table(table, Path(out) / f"part-{f:05d}.zstd.parquet", compression="zstd",
-                   compression_level=1)
+                   compression_level=1, row_group_size=row_group_size)
     return len(row)
 
 
@@ -52,6 +53,10 @@ def main():
     ap.add_argument("--threads", type=int, default=0, help="reader threads (0 = visible CPUs)")
     ap.add_argument("--repeat", type=int, default=2)
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--row-group-size", type=int, default=0,
+                    help="rows per Parquet row group (0 = one group per file, pyarrow's default "
+                         "below 1 Mi rows...): fewer files than reader threads are then decoded "
+                         "one task per row group")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     cpus = len(os.sched_getaffinity(0))
@@ -62,8 +67,8 @@ def main():
         {"num_sites": a.m, "samples": [f"S{k:07d}" for k in range(a.n)]}))
     bounds = np.linspace(0, a.m, a.files + 1).astype(int)
     t0 = time.perf_counter()
-    jobs = [(str(d / "in"), f, int(bounds[f]), int(bounds[f + 1]), a.n, 1)
-            for f in range(a.files)]
+    jobs = [(str(d / "in"), f, int(bounds[f]), int(bounds[f + 1]), a.n, 1,
+             a.row_group_size or None) for f in range(a.files)]
     triples = 0
     with ProcessPoolExecutor(max(1, min(cpus, 16))) as ex:
         for k, count in enumerate(ex.map(write_part, jobs)):
@@ -78,7 +83,7 @@ def main():
     print(f"wrote {a.n}x{a.m}: {triples} triples, {size / 1e6:.0f} MB zstd parquet in "
           f"{a.files} files, {report['generate_s']:.1f}s on {cpus} CPUs", flush=True)
     for rep in range(a.repeat):
-        for pack in ("host", "device"):
+        for pack in ("host", "device", "auto"):
             t0 = time.perf_counter()
             p = subprocess.run([str(ROOT / "cuking_amd/bin/cuking"), "--input_uri", str(d / "in"),
                                 "--output_uri", str(d / f"out_{pack}"), f"--pack={pack}",
@@ -91,7 +96,8 @@ def main():
             phases = dict((k.strip(), float(v)) for k, v in
                           re.findall(r"^(.*?)\.\.\.\.* ?\(([\d.]+)s\)", p.stdout, flags=re.M))
             summary = json.loads(p.stdout.strip().splitlines()[-1])
-            run = {"pack": pack, "wall_s": wall, "phases_s": phases,
+            run = {"pack": pack, "pack_chosen": summary["pack"],
+                   "decode_tasks": summary.get("decode_tasks"), "wall_s": wall, "phases_s": phases,
                    "read_pack_seconds": summary["read_pack_seconds"],
                    "triples_per_second": summary["triples_per_second"],
                    "decode_thread_seconds": summary["decode_thread_seconds"],
