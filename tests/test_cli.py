@@ -729,12 +729,12 @@ def test_hundred_million_triples_through_both_packs(tmp_path_factory):
     file, the decode handed out per row group (8 files, 16 reader threads), and
     the device pack not slower than the host pack beyond the noise of a shared
     box (profiles/r02_pack_pipeline.txt: equal at this size, +37 % at 1e9)."""
-    import importlib.util
+    import sys
     from concurrent.futures import ProcessPoolExecutor
-    spec = importlib.util.spec_from_file_location(
-        "cli_timing", Path(__file__).resolve().parent.parent / "tools" / "cli_timing.py")
-    cli_timing = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(cli_timing)
+    tools = str(Path(__file__).resolve().parent.parent / "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)       # (the workers import the generator by module name)
+    import cli_timing
     d = tmp_path_factory.mktemp("pack1e8")
     n, m, files = 2000, 50_000, 8
     (d / "in").mkdir()
