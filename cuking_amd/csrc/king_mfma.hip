@@ -923,22 +923,6 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
             : "s"(dst), "v"(lane16), "s"(src)
             : "memory", "m0");
     };
-    // (experiment CUKING_N4_DMA_MODE=1: both requests of a slice land in ONE LDS
-    //  slice, 1 KiB apart through the immediate offset, so M0 is the same for
-    //  the two and can be written ahead of them)
-    [[maybe_unused]] auto n4_m0 = [&](const N4Addr &pa, int c) {
-      const uint32_t dst = pa.dst + c * (kSliceU4 * 16);
-      asm volatile("s_mov_b32 m0, %0" : : "s"(dst) : "memory", "m0");
-    };
-    [[maybe_unused]] auto n4_issue_m0 = [&](const N4Addr &pa, int c, int half) {
-      if (ABLATE == 1 || ABLATE == 2) return;
-      const uint4 *src = pa.src + (uint64_t)c * s_stride;
-      if (half)
-        asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" : : "v"(lane16), "s"(src)
-                     : "memory");
-      else
-        asm volatile("global_load_lds_dwordx4 %0, %1" : : "v"(lane16), "s"(src) : "memory");
-    };
     // Stage hand-over, once per k-step (in its third slice, before the first LDS
     // read of the next stage).  Requests of this wavefront still in flight then:
     // stages s + 1 .. s + 3 and the 4 requests of stage s + 4 that slices 0 and 1
@@ -999,25 +983,6 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       acc[bi][bj][Q] = mma<1>(Fa[KA][bi], Fb[KB][bj], acc[bi][bj][Q]);
 // A group of four MFMAs that also carries the slice's two DMA requests (in gaps
 // of their own) and the H columns of the next slice.
-#ifndef CUKING_N4_DMA_MODE
-#define CUKING_N4_DMA_MODE 0  // (experiments: 1 = M0 written one MFMA ahead of its request)
-#endif
-#if CUKING_N4_DMA_MODE == 1
-#define N4_DMA_GROUP(Q, K, NXT, C)                                             \
-    n4_m0(pa, C);                                                              \
-    _Pragma("unroll") for (int r = 0; r < 2; ++r) {                            \
-      n4_issue_m0(pa, C, r);                                                   \
-      acc[0][r][Q] = mma<1>(Fa[K][0], Fb[K][r], acc[0][r][Q]);                 \
-      __builtin_amdgcn_sched_barrier(0);                                       \
-    }                                                                          \
-    N4_PIN_RAW_B(NXT)                                                          \
-    N4_BUILD_B(0, NXT, mH)                                                     \
-    _Pragma("unroll") for (int r = 0; r < 2; ++r)                              \
-      acc[1][r][Q] = mma<1>(Fa[K][1], Fb[K][r], acc[1][r][Q]);                 \
-    CUKING_PACE(2, 4)                                                          \
-    N4_PIN_B(0)                                                                \
-    __builtin_amdgcn_sched_barrier(0);
-#else
 #define N4_DMA_GROUP(Q, K, NXT, C)                                             \
     _Pragma("unroll") for (int r = 0; r < 2; ++r) {                            \
       n4_issue(pa, C, r);                                                      \
@@ -1031,7 +996,6 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     CUKING_PACE(2, 4)                                                          \
     N4_PIN_B(0)                                                                \
     __builtin_amdgcn_sched_barrier(0);
-#endif
 // A group that issues the LDS reads of the slice after next (behind the stage
 // hand-over if SYNC) and builds the H rows of the next slice.
 #define N4_READ_GROUP(Q, KA, KB, CUR, NXT, RBUF, RSLICE, SYNC)                 \

@@ -374,11 +374,29 @@ Status Run(const Flags &flags) {
     return InvalidArgument("--dump_bitset needs input tables, not --synthetic");
   // (a synthetic cohort is generated on the GPU: from here on it is a bitset
   //  that already sits in device memory, like a device-packed one)
-  // --pack=auto: the device pack wins while the GPU's atomics keep up with the
-  // readers (profiles/r02_pack_pipeline.txt: up to ~32 reader threads feeding one
-  // GPU; beyond that the host's cores pack faster than one GPU's atomic units).
-  const std::string pack_mode =
-      flags.pack != "auto" ? flags.pack : flags.num_reader_threads <= 32 ? "device" : "host";
+  // --pack=auto is resolved once the input is listed (below): the device pack
+  // pays ~0.1 s of set-up (page-locked rings, streams) and wins while the GPU's
+  // atomics keep up with the readers.
+  std::string pack_mode = flags.pack;
+  std::vector<std::pair<std::string, size_t>> input_files;
+  if (!synthetic) {  // (listed before anything is allocated: the pack mode depends on it)
+    std::cout << "Listing input files..." << std::flush;
+    RETURN_IF_ERROR(ListParquetFiles(input_dir, &input_files));
+    Done(&sw);
+    if (input_files.empty()) return FailedPrecondition("No input files found");  // :542-544
+    std::cout << "Found " << input_files.size() << " input files." << std::endl;
+  }
+  if (pack_mode == "auto") {
+    // Measured on MI355X boxes (profiles/r03_pack_pipeline.txt): with up to ~32
+    // reader threads per GPU and an input of a gigabyte or more the pipelined
+    // device pack is ahead (1e9 triples: +37 %); below that its set-up is not
+    // amortised (1e8 triples: 0.27 s against 0.20 s), and beyond ~32 threads the
+    // host's cores outrun one GPU's atomic units.
+    size_t input_bytes = 0;
+    for (const auto &f : input_files) input_bytes += f.second;
+    pack_mode = (flags.num_reader_threads <= 32 && input_bytes >= (size_t(1) << 30)) ? "device"
+                                                                                      : "host";
+  }
   const bool pack_on_device = (pack_mode == "device" || synthetic) && !dump_only;
 
   DeviceBuffers buf;
@@ -411,14 +429,6 @@ Status Run(const Flags &flags) {
       dump_only ? dump_bits.data() : static_cast<uint64_t *>(buf.host_bits);
   Done(&sw);
 
-  std::vector<std::pair<std::string, size_t>> input_files;
-  if (!synthetic) {
-    std::cout << "Listing input files..." << std::flush;
-    RETURN_IF_ERROR(ListParquetFiles(input_dir, &input_files));
-    Done(&sw);
-    if (input_files.empty()) return FailedPrecondition("No input files found");  // :542-544
-    std::cout << "Found " << input_files.size() << " input files." << std::endl;
-  }
   const bool device_pack = pack_on_device && !synthetic;  // triples packed by the GPU
   // Decode tasks: one per (file, row group) when the files are fewer than the
   // reader threads -- the reference hands out whole files (cuking.cu:550-553),

@@ -755,18 +755,23 @@ def test_hundred_million_triples_through_both_packs(tmp_path_factory):
             assert s_["triples"] == triples and s_["pack"] == pack
             assert s_["decode_tasks"] > files            # row groups, not files
             best[pack] = min(best.get(pack, 1e9), s_["read_pack_seconds"])
+            if rep == 1:
+                print(pack, {k: s_[k] for k in ("read_pack_seconds", "decode_thread_seconds",
+                                                "pack_thread_seconds", "device_pack_thread_seconds")})
             outputs[pack] = (d / f"out_{pack}" / "part-00000.snappy.parquet").read_bytes()
     assert outputs["host"] == outputs["device"] and len(outputs["host"]) > 0
     print(f"1e8 triples: host pack {best['host']:.3f} s, device pack {best['device']:.3f} s")
-    assert best["device"] <= 1.3 * best["host"], best
-    # --pack=auto takes the device pack at 16 reader threads, the host pack at 48
-    p = run_cli("--input_uri", d / "in", "--output_uri", d / "out_auto", "--num_reader_threads=16",
-                "--kin_threshold=0.05", check=True)
-    assert json.loads(p.stdout.strip().splitlines()[-1])["pack"] == "device"
-    p = run_cli("--input_uri", d / "in", "--output_uri", d / "out_auto48",
-                "--num_reader_threads=48", "--kin_threshold=0.05", check=True)
-    assert json.loads(p.stdout.strip().splitlines()[-1])["pack"] == "host"
-    assert (d / "out_auto48" / "part-00000.snappy.parquet").read_bytes() == outputs["host"]
+    # At this size the device pack's set-up (page-locked rings, streams: ~0.1 s) is
+    # not amortised; it must stay within that of the host pack (it overtakes it from
+    # about 5e8 triples on: profiles/r03_pack_pipeline.txt).
+    assert best["device"] <= best["host"] + 0.15, best
+    # --pack=auto: the host pack for an input this small (0.2 GB of Parquet), at any
+    # thread count
+    for threads in (16, 48):
+        p = run_cli("--input_uri", d / "in", "--output_uri", d / f"out_auto{threads}",
+                    f"--num_reader_threads={threads}", "--kin_threshold=0.05", check=True)
+        assert json.loads(p.stdout.strip().splitlines()[-1])["pack"] == "host"
+        assert (d / f"out_auto{threads}" / "part-00000.snappy.parquet").read_bytes() == outputs["host"]
 
 
 @pytest.mark.gpu
