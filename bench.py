@@ -498,8 +498,13 @@ def dist_workload(args, env, ctx, key, n, m, thr, steps, warmup, headline):
         torch.cuda.synchronize()
 
     balance = {"applied": False}
+    ctx.timing_reset()
+    first_prepare_ms = None
     for w in range(warmup):
         if w == warmup - 1:
+            early = ctx.timing_collect()        # (the cohort's one conversion, if it is in here)
+            if early.prepare_launches:
+                first_prepare_ms = early.prepare_ms / early.prepare_launches
             ctx.timing_reset()          # the last warm-up pass doubles as calibration
         step()
     if pipelined:
@@ -511,6 +516,8 @@ def dist_workload(args, env, ctx, key, n, m, thr, steps, warmup, headline):
         # percent); with equal ranges the slowest sets the pace.  Re-cut the tile
         # ranges in proportion to what each rank just measured for itself.
         cal = ctx.timing_collect()
+        if cal.prepare_launches and first_prepare_ms is None:
+            first_prepare_ms = cal.prepare_ms / cal.prepare_launches
         rate = torch.tensor([(my_tiles[1] - my_tiles[0]) / max(cal.king_ms, 1e-6)],
                             dtype=torch.float64, device=host_or_dev)
         rates = [torch.zeros_like(rate) for _ in range(world)]
@@ -623,7 +630,8 @@ def dist_workload(args, env, ctx, key, n, m, thr, steps, warmup, headline):
         king_ms = timing.king_ms / max(steps, 1)
         roofline = roofline_block(
             args, ctx, launch_pairs=pairs * share, sites=m, wps=wps, thr=thr, king_ms=king_ms,
-            prepare_ms=timing.prepare_ms / max(timing.prepare_launches, 1),
+            prepare_ms=(timing.prepare_ms / timing.prepare_launches if timing.prepare_launches
+                        else (first_prepare_ms or 0.0)),
             launches=timing.king_launches, workload_key=f"{n}x{m}", clock_mhz=None,
             use_profile=False)
         roofline["note_rank"] = ("rank 0's launches over its share of the pairs "
