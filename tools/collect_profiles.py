@@ -24,7 +24,16 @@ dst = ROOT / "profiles"
 bench = json.loads((src / "bench.json").read_text())
 cfg = bench["config"]
 key = f"{cfg['samples']}x{cfg['sites']}"
-stats = glob.glob(str(src / "trace" / "**" / "*kernel_stats.csv"), recursive=True)[0]
+import os
+
+
+def newest(pattern):
+    # (gpurun merges every run of a tag into the same directory: take the latest)
+    files = glob.glob(pattern, recursive=True)
+    return max(files, key=os.path.getmtime) if files else None
+
+
+stats = newest(str(src / "trace" / "**" / "*kernel_stats.csv"))
 shutil.copy(stats, dst / f"{rnd}_kernel_stats_{suffix}.csv")
 shutil.copy(src / "pmc_summary.txt", dst / f"{rnd}_pmc_summary_{suffix}.txt")
 (dst / f"{rnd}_bench_{suffix}.json").write_text(json.dumps(bench, indent=1) + "\n")
@@ -40,9 +49,9 @@ def short_name(name):
 
 # per-dispatch durations of every cuking kernel, in launch order
 per_kernel = {}
-traces = glob.glob(str(src / "trace" / "**" / "*kernel_trace.csv"), recursive=True)
-if traces:
-    rows = sorted(csv.DictReader(open(traces[0])), key=lambda r: int(r["Start_Timestamp"]))
+trace = newest(str(src / "trace" / "**" / "*kernel_trace.csv"))
+if trace:
+    rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
     for r in rows:
         if "cuking" in r["Kernel_Name"]:
             per_kernel.setdefault(short_name(r["Kernel_Name"]), []).append(
