@@ -1227,19 +1227,18 @@ cuking_status cuking_timing_collect(cuking_ctx *ctx, double *king_ms,
         ++n;
       }
     if (n) {
-      bool both = false;
-      for (int k = 0; k < 6; ++k) both = both || (sum[0][k] != 0 && sum[1][k] != 0);
-      const double per_row = both ? steps / 2 : steps;
+      // five-product loop: alternating k-steps without / with a hand-over (6 phases);
+      // four-product loop: per k-step three slices without and one with (4 groups)
       for (int r = 0; r < 2; ++r) {
         double t = 0;
         for (int k = 0; k < 6; ++k) t += sum[r][k];
         if (t == 0) continue;
         fprintf(stderr,
-                "mfma stamps (%d workgroups, k-steps %s hand-over): cycles per k-step  f0 %.0f | "
-                "dma %.0f | f1 %.0f | f2 %.0f | sync %.0f | f3 %.0f | total %.0f\n",
-                n, r ? "with" : "without", sum[r][0] / per_row, sum[r][1] / per_row,
-                sum[r][2] / per_row, sum[r][3] / per_row, sum[r][4] / per_row, sum[r][5] / per_row,
-                t / per_row);
+                "mfma stamps (%d workgroups, row %d = %s hand-over): cycles per k-step of the "
+                "tile  p0 %.0f | p1 %.0f | p2 %.0f | p3 %.0f | p4 %.0f | p5 %.0f | total %.0f\n",
+                n, r, r ? "with" : "without", sum[r][0] / steps, sum[r][1] / steps,
+                sum[r][2] / steps, sum[r][3] / steps, sum[r][4] / steps, sum[r][5] / steps,
+                t / steps);
       }
     }
   }

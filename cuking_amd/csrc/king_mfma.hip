@@ -1026,6 +1026,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
 // go out; SYNC: stage hand-over in front of the reads.
 #define N4_SLICE(CUR, NXT, RBUF, RSLICE, SYNC, C)                              \
     {                                                                          \
+      CUKING_STAMP_ROW(SYNC)                                                   \
       /* hi = H_i.D_j; T of this slice from its own raw words */               \
       N4_PIN_RAW_A(CUR) N4_PIN_RAW_B(CUR)                                      \
       N4_BUILD_A(2, CUR, mT) N4_BUILD_B(2, CUR, mT)                            \
@@ -1033,12 +1034,16 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       CUKING_PACE(4, 4)                                                        \
       N4_PIN_A(2) N4_PIN_B(2)                                                  \
       __builtin_amdgcn_sched_barrier(0);                                       \
+      CUKING_STAMP(0)                                                          \
       /* hj = D_i.H_j */                                                       \
       N4_READ_GROUP(1, 1, 0, CUR, NXT, RBUF, RSLICE, SYNC)                     \
+      CUKING_STAMP(1)                                                          \
       /* dd = D_i.D_j */                                                       \
       N4_DMA_GROUP(2, 1, NXT, C)                                               \
+      CUKING_STAMP(2)                                                          \
       /* q = T_i.T_j */                                                        \
       N4_LAST_GROUP(3, 2, 2, NXT)                                              \
+      CUKING_STAMP(3)                                                          \
     }
     zero_acc();
     if constexpr (HH5) {
@@ -1065,6 +1070,13 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     // (all its reads were issued before the hand-over of k-step s - 1)
     N4Addr pa = n4_addr(NSTAGE - 1, NSTAGE - 1);
     CUKING_TL(2 + 5 * tl_seg)
+#ifdef CUKING_MFMA_STAMPS
+    // groups hi | hj + reads (+ hand-over) | dd + requests | q, summed over the
+    // three slices of a k-step without a hand-over (row 0) and the one with (row 1)
+    unsigned long long stamp_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+    [[maybe_unused]] int stamp_row = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
     for (uint32_t step = 0; step < num_steps; ++step) {
       const uint32_t nbuf = buf == NSTAGE - 1 ? 0 : buf + 1;
       N4_SLICE(0, 1, buf, 2, false, 0)
@@ -1074,6 +1086,16 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       pa = n4_addr(step + NSTAGE, buf);
       buf = nbuf;
     }
+#ifdef CUKING_MFMA_STAMPS
+    if (!SPLIT && a.split_scratch != nullptr && blockIdx.x < 1024 && threadIdx.x == 0) {
+      unsigned long long *dbg =
+          reinterpret_cast<unsigned long long *>(a.split_scratch) + (size_t)blockIdx.x * 16;
+      for (int k = 0; k < 6; ++k) dbg[k] = stamp_sum[k];
+      for (int k = 0; k < 6; ++k) dbg[8 + k] = stamp_sum[6 + k];
+      dbg[6] = num_steps;
+      dbg[7] = 0x5354414D50ull;  // "STAMP"
+    }
+#endif
 #undef N4_READ
 #undef N4_PIN4
 #undef N4_PINF
