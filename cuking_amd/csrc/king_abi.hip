@@ -1242,6 +1242,27 @@ cuking_status cuking_timing_collect(cuking_ctx *ctx, double *king_ms,
       }
     }
   }
+  // four-product loop: 4 slices x 4 groups (hi | hj + reads | dd + requests | q)
+  for (auto &e : ctx->split_scratch) {
+    std::vector<unsigned long long> h(1024 * 32);
+    uint32_t *scratch = e.second + mfma_split_counter_bytes(ctx->split_wgs) / sizeof(uint32_t);
+    if (hipMemcpy(h.data(), scratch, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) break;
+    double sum[16] = {}, steps = 0;
+    int n = 0;
+    for (int b = 0; b < 1024; ++b)
+      if (h[b * 32 + 25] == 0x5354414D5034ull) {
+        for (int k = 0; k < 16; ++k) sum[k] += (double)h[b * 32 + (k < 7 ? k : k + 1)];
+        steps += (double)h[b * 32 + 24];
+        ++n;
+      }
+    if (n)
+      for (int c = 0; c < 4; ++c)
+        fprintf(stderr,
+                "mfma4 stamps (%d workgroups) slice %d: cycles per k-step  hi %.0f | hj+reads%s %.0f | "
+                "dd+requests %.0f | q %.0f\n",
+                n, c, sum[4 * c] / steps, c == 2 ? "+hand-over" : "", sum[4 * c + 1] / steps,
+                sum[4 * c + 2] / steps, sum[4 * c + 3] / steps);
+  }
 #endif
   if (king_ms) *king_ms = a;
   if (king_launches) *king_launches = na;

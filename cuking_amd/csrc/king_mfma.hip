@@ -223,9 +223,11 @@ void timeline_arm(uint32_t whole, uint32_t blocks);
     stamp_last = now_;                                                         \
   }
 #define CUKING_STAMP_ROW(SYNC) stamp_row = (SYNC) ? 6 : 0;
+#define CUKING_STAMP_SLICE(C) stamp_row = 4 * (C);
 #else
 #define CUKING_STAMP(K)
 #define CUKING_STAMP_ROW(SYNC)
+#define CUKING_STAMP_SLICE(C)
 #endif
 
 // Tickets: one per workgroup and pass (the full form makes two).
@@ -1026,11 +1028,15 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
 // go out; SYNC: stage hand-over in front of the reads.
 #define N4_SLICE(CUR, NXT, RBUF, RSLICE, SYNC, C)                              \
     {                                                                          \
-      CUKING_STAMP_ROW(SYNC)                                                   \
+      CUKING_STAMP_SLICE(C)                                                    \
       /* hi = H_i.D_j; T of this slice from its own raw words */               \
       N4_PIN_RAW_A(CUR) N4_PIN_RAW_B(CUR)                                      \
       N4_BUILD_A(2, CUR, mT) N4_BUILD_B(2, CUR, mT)                            \
       N4_MMA(0, 0, 1)                                                          \
+      /* (last slice: the next k-step's request addresses -- a dependent chain  \
+         of ~10 scalar instructions -- among this group's MFMAs, not behind the \
+         k-step where nothing covers them) */                                  \
+      if ((C) == 3 && !CUKING_N4_ADDR_LATE) pa_next = n4_addr(step + NSTAGE, buf); \
       CUKING_PACE(4, 4)                                                        \
       N4_PIN_A(2) N4_PIN_B(2)                                                  \
       __builtin_amdgcn_sched_barrier(0);                                       \
@@ -1071,29 +1077,61 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     N4Addr pa = n4_addr(NSTAGE - 1, NSTAGE - 1);
     CUKING_TL(2 + 5 * tl_seg)
 #ifdef CUKING_MFMA_STAMPS
-    // groups hi | hj + reads (+ hand-over) | dd + requests | q, summed over the
-    // three slices of a k-step without a hand-over (row 0) and the one with (row 1)
-    unsigned long long stamp_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+    // groups hi | hj + reads (+ hand-over in slice 2) | dd + requests | q of each of
+    // the four slices of a k-step
+    unsigned long long stamp_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
     [[maybe_unused]] int stamp_row = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
 #endif
-    for (uint32_t step = 0; step < num_steps; ++step) {
-      const uint32_t nbuf = buf == NSTAGE - 1 ? 0 : buf + 1;
-      N4_SLICE(0, 1, buf, 2, false, 0)
-      N4_SLICE(1, 0, buf, 3, false, 1)
-      N4_SLICE(0, 1, nbuf, 0, true, 2)
-      N4_SLICE(1, 0, nbuf, 1, false, 3)
-      pa = n4_addr(step + NSTAGE, buf);
-      buf = nbuf;
+    // One k-step; two per loop trip (the trip's back edge and counter updates cost
+    // ~100 cycles with nothing to cover them: stamps, profiles/r03_stamps_n4.txt).
+#ifndef CUKING_N4_KSTEPS_PER_TRIP
+#define CUKING_N4_KSTEPS_PER_TRIP 2  // (A/B: 1)
+#endif
+#ifndef CUKING_N4_ADDR_LATE
+#define CUKING_N4_ADDR_LATE 0        // (A/B: 1 = next k-step's addresses behind the k-step)
+#endif
+#define N4_KSTEP                                                               \
+    {                                                                          \
+      const uint32_t nbuf = buf == NSTAGE - 1 ? 0 : buf + 1;                   \
+      N4Addr pa_next;                                                          \
+      N4_SLICE(0, 1, buf, 2, false, 0)                                         \
+      N4_SLICE(1, 0, buf, 3, false, 1)                                         \
+      N4_SLICE(0, 1, nbuf, 0, true, 2)                                         \
+      N4_SLICE(1, 0, nbuf, 1, false, 3)                                        \
+      if (CUKING_N4_ADDR_LATE) pa_next = n4_addr(step + NSTAGE, buf);          \
+      pa = pa_next;                                                            \
+      buf = nbuf;                                                              \
+      ++step;                                                                  \
     }
+    uint32_t step = 0;
+#if CUKING_N4_KSTEPS_PER_TRIP == 4
+    while (step + 3 < num_steps) {
+      N4_KSTEP
+      N4_KSTEP
+      N4_KSTEP
+      N4_KSTEP
+    }
+    while (step < num_steps) N4_KSTEP
+#elif CUKING_N4_KSTEPS_PER_TRIP == 2
+    while (step + 1 < num_steps) {
+      N4_KSTEP
+      N4_KSTEP
+    }
+    if (step < num_steps) N4_KSTEP
+#else
+    while (step < num_steps) N4_KSTEP
+#endif
+#undef N4_KSTEP
 #ifdef CUKING_MFMA_STAMPS
     if (!SPLIT && a.split_scratch != nullptr && blockIdx.x < 1024 && threadIdx.x == 0) {
+      // (32 words per workgroup; word 7 stays clear of the five-product loop's mark)
       unsigned long long *dbg =
-          reinterpret_cast<unsigned long long *>(a.split_scratch) + (size_t)blockIdx.x * 16;
-      for (int k = 0; k < 6; ++k) dbg[k] = stamp_sum[k];
-      for (int k = 0; k < 6; ++k) dbg[8 + k] = stamp_sum[6 + k];
-      dbg[6] = num_steps;
-      dbg[7] = 0x5354414D50ull;  // "STAMP"
+          reinterpret_cast<unsigned long long *>(a.split_scratch) + (size_t)blockIdx.x * 32;
+      for (int k = 0; k < 16; ++k) dbg[k < 7 ? k : k + 1] = stamp_sum[k];
+      dbg[7] = 0;
+      dbg[24] = num_steps;
+      dbg[25] = 0x5354414D5034ull;  // "STAMP4"
     }
 #endif
 #undef N4_READ
