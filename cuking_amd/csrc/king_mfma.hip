@@ -904,6 +904,22 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       asm volatile("" : "+s"(pa.src), "+s"(pa.dst));
       return pa;
     };
+    // ... of the stage after the one `pa` names: one k-step further unless that was
+    // the last (then the same rows again: clamped repeats), into buffer `buf` --
+    // a compare, a select and two adds instead of n4_addr's 64-bit multiply chain
+    // (65 cycles of a k-step in the stamps, profiles/r03_stamps_n4.txt).
+    const uint32_t kstep_bytes = 8 * s_stride * 16;  // (< 2^32: 128 B x stored samples)
+    auto n4_next = [&](const N4Addr &cur, uint32_t step, uint32_t buf) {
+#ifdef CUKING_N4_ADDR_MUL  // (A/B)
+      return n4_addr(step, buf);
+#endif
+      N4Addr pa;
+      const uint32_t adv = step < num_steps ? kstep_bytes : 0u;
+      pa.src = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(cur.src) + adv);
+      pa.dst = l_wave4 + buf * (kStageN4 * 16);
+      asm volatile("" : "+s"(pa.src), "+s"(pa.dst));
+      return pa;
+    };
     auto n4_issue = [&](const N4Addr &pa, int c, int half) {
       if (ABLATE == 1 || ABLATE == 2) return;
       const uint4 *src = pa.src + (uint64_t)c * s_stride;
@@ -1036,7 +1052,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       /* (last slice: the next k-step's request addresses -- a dependent chain  \
          of ~10 scalar instructions -- among this group's MFMAs, not behind the \
          k-step where nothing covers them) */                                  \
-      if ((C) == 3 && !CUKING_N4_ADDR_LATE) pa_next = n4_addr(step + NSTAGE, buf); \
+      if ((C) == 3 && !CUKING_N4_ADDR_LATE) pa_next = n4_next(pa, step + NSTAGE, buf); \
       CUKING_PACE(4, 4)                                                        \
       N4_PIN_A(2) N4_PIN_B(2)                                                  \
       __builtin_amdgcn_sched_barrier(0);                                       \
@@ -1083,10 +1099,10 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     [[maybe_unused]] int stamp_row = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
 #endif
-    // One k-step; two per loop trip (the trip's back edge and counter updates cost
+    // One k-step; four per loop trip (the trip's back edge and counter updates cost
     // ~100 cycles with nothing to cover them: stamps, profiles/r03_stamps_n4.txt).
 #ifndef CUKING_N4_KSTEPS_PER_TRIP
-#define CUKING_N4_KSTEPS_PER_TRIP 2  // (A/B: 1)
+#define CUKING_N4_KSTEPS_PER_TRIP 4  // (A/B: 1, 2: configs[2] 540 -> 529 -> 526 ms)
 #endif
 #ifndef CUKING_N4_ADDR_LATE
 #define CUKING_N4_ADDR_LATE 0        // (A/B: 1 = next k-step's addresses behind the k-step)
@@ -1099,7 +1115,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
       N4_SLICE(1, 0, buf, 3, false, 1)                                         \
       N4_SLICE(0, 1, nbuf, 0, true, 2)                                         \
       N4_SLICE(1, 0, nbuf, 1, false, 3)                                        \
-      if (CUKING_N4_ADDR_LATE) pa_next = n4_addr(step + NSTAGE, buf);          \
+      if (CUKING_N4_ADDR_LATE) pa_next = n4_next(pa, step + NSTAGE, buf);      \
       pa = pa_next;                                                            \
       buf = nbuf;                                                              \
       ++step;                                                                  \
