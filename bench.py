@@ -491,7 +491,9 @@ def dist_workload(args, env, ctx, key, n, m, thr, steps, warmup, headline):
             if mode != "resident":
                 ctx.invalidate()
             gathered[0], _ = all_pairs_king(compute_tiles, num_tiles, bits,
-                                            broadcast=mode != "resident")
+                                            broadcast=mode != "resident",
+                                            record_capacity=args.max_results,
+                                            device_counts=device_gather)
 
     def barrier():
         dist.barrier()

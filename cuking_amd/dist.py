@@ -16,9 +16,11 @@ exactly two exchange steps:
 
 A rank whose local work fails (an exception from the kernel call, an
 out-of-memory, ...) must not leave the others waiting inside the gather until
-the communicator times out: before step 2 every rank contributes a status word
-(``agree_on_status``; in the pipelined gather it rides in the header row of the
-one all-gather), and a failure anywhere raises on every rank -- the original
+the communicator times out: every rank contributes a status word that rides in
+the counts exchange of the gather itself (the header row of the device-side and
+pipelined gathers, the meta vector of the host-side one; ``agree_on_status``, a
+collective of its own, remains for callers that cannot say which form of gather
+their ranks take), and a failure anywhere raises on every rank -- the original
 exception on the rank that had it, ``RemoteRankError`` on the others.
 
 Every tile costs the same (diagonal tiles are evaluated in full and masked at
@@ -113,20 +115,36 @@ def broadcast_bitset(bit_sets, src: int = 0, group=None) -> None:
     dist.broadcast(bit_sets, src=src, group=group)
 
 
+def _raise_if_failed(failed_ranks, rank: int, error: Optional[BaseException]) -> None:
+    if error is not None:
+        raise error
+    if failed_ranks:
+        raise RemoteRankError(f"rank(s) {failed_ranks} failed; rank {rank} stops with them")
+
+
 def gather_results(local, count: int, overflow: int, dst: int = 0,
-                   group=None) -> Optional[np.ndarray]:
+                   group=None, error: Optional[BaseException] = None,
+                   device=None) -> Optional[np.ndarray]:
     """Exchange step 2.  ``local`` is this rank's [capacity, 6] int32 tensor of
     KingResult records, the first ``count`` valid.  Returns the sorted records
     of all ranks on ``dst`` (None elsewhere); raises on every rank if any rank
-    overflowed (cuking.cu:747-751)."""
+    overflowed (cuking.cu:747-751).  ``error``: the exception this rank's pass
+    raised, if any (``local`` may then be None; ``device`` says where its part of
+    the exchange lives): the status rides in the counts exchange, and a failure
+    anywhere raises on every rank -- no separate agreement collective."""
     import torch
     import torch.distributed as dist
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
+    if local is None:
+        local = torch.zeros((1, 6), dtype=torch.int32, device=device or "cpu")
+        count = overflow = 0
     meta_dev = "cpu" if dist.get_backend(group) == "gloo" else local.device
-    meta = torch.tensor([count, overflow], dtype=torch.int64, device=meta_dev)
+    meta = torch.tensor([count, overflow, 0 if error is None else 1], dtype=torch.int64,
+                        device=meta_dev)
     metas = [torch.zeros_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta, group=group)
+    _raise_if_failed([r for r, m in enumerate(metas) if int(m[2])], rank, error)
     counts = [int(m[0]) for m in metas]
     if any(int(m[1]) for m in metas):
         raise ResourceExhaustedError(
@@ -149,7 +167,8 @@ def gather_results(local, count: int, overflow: int, dst: int = 0,
 
 
 def gather_results_device(local, index_flag, dst: int = 0, group=None,
-                          fast_rows: int = 8192) -> Optional[np.ndarray]:
+                          fast_rows: int = 8192, error: Optional[BaseException] = None,
+                          capacity: Optional[int] = None, device=None) -> Optional[np.ndarray]:
     """Exchange step 2 without a host round trip before the collective.
     ``index_flag`` is the kernel's own device tensor [count, overflow] (int32).
     Fast path: ONE all-gather of a fixed block per rank -- a header row with
@@ -161,19 +180,26 @@ def gather_results_device(local, index_flag, dst: int = 0, group=None,
     import torch.distributed as dist
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
+    if local is None:
+        # this rank's pass failed (``error``): it still takes part, with an empty
+        # block of the shape the others use (``capacity`` = their record buffers')
+        local = torch.zeros((capacity, 6), dtype=torch.int32, device=device)
+        index_flag = torch.zeros(2, dtype=torch.int32, device=device)
     fast_rows = min(fast_rows, local.shape[0])
     block = torch.empty((fast_rows + 1, 6), dtype=torch.int32, device=local.device)
     block[0, :2] = index_flag
+    block[0, 2] = 0 if error is None else 1      # status, read with the counts
     block[1:] = local[:fast_rows]
     parts = [torch.empty_like(block) for _ in range(world)]
     dist.all_gather(parts, block, group=group)     # (gloo has no all_gather_into_tensor)
     blocks = torch.stack(parts)
     if rank == dst:
         host = blocks.cpu().numpy()              # the one synchronisation point
-        heads = host[:, 0, :2]
+        heads = host[:, 0, :3]
     else:
         host = None
-        heads = blocks[:, 0, :2].cpu().numpy()
+        heads = blocks[:, 0, :3].cpu().numpy()
+    _raise_if_failed([r for r in range(world) if heads[r, 2]], rank, error)
     counts = [int(c) for c in heads[:, 0]]
     if heads[:, 1].any():
         raise ResourceExhaustedError(
@@ -273,7 +299,8 @@ class PipelinedGather:
 
 def all_pairs_king(compute_tiles: Callable, num_tiles: int, bit_sets,
                    src: int = 0, dst: int = 0, group=None,
-                   broadcast: bool = True):
+                   broadcast: bool = True, record_capacity: Optional[int] = None,
+                   device_counts: Optional[bool] = None):
     """One sharded pass.  ``compute_tiles(bit_sets, tile_begin, tile_end)``
     must return (records tensor [cap, 6] int32, count, overflow) for its tile
     range -- or (records tensor, index_flag device tensor [count, overflow]),
@@ -288,13 +315,26 @@ def all_pairs_king(compute_tiles: Callable, num_tiles: int, bit_sets,
     out, error = None, None
     try:
         out = compute_tiles(bit_sets, begin, end)
-    except Exception as e:  # noqa: BLE001 - re-raised by agree_on_status, on every rank
+    except Exception as e:  # noqa: BLE001 - re-raised on every rank by the gather
         error = e
-    agree_on_status(error, group=group, device=getattr(bit_sets, "device", None))
-    if len(out) == 2:
-        return gather_results_device(out[0], out[1], dst=dst, group=group), (begin, end)
-    local, count, overflow = out
-    return gather_results(local, count, overflow, dst=dst, group=group), (begin, end)
+    dev = getattr(bit_sets, "device", None)
+    # The status of the pass rides in the gather's counts exchange.  A rank whose
+    # pass failed has nothing to show which form of gather the others take, nor
+    # the shape of their blocks: the caller says (``device_counts``: compute_tiles
+    # returns the kernel's device counters; ``record_capacity``: rows of every
+    # rank's record buffer).  Without that the ranks agree in a collective of
+    # their own first.
+    known = device_counts is not None and (not device_counts or record_capacity is not None)
+    if not known:
+        agree_on_status(error, group=group, device=dev)
+        device_counts = len(out) == 2
+    if device_counts:
+        local, flag = out if out is not None else (None, None)
+        return gather_results_device(local, flag, dst=dst, group=group, error=error,
+                                     capacity=record_capacity, device=dev), (begin, end)
+    local, count, overflow = out if out is not None else (None, 0, 0)
+    return gather_results(local, count, overflow, dst=dst, group=group, error=error,
+                          device=dev), (begin, end)
 
 
 # ---------------------------------------------------------------------------
@@ -381,9 +421,7 @@ def all_pairs_king_staged(ops, num_samples: int, tile: int, bit_sets,
             local, count, overflow = ops.finish()
         except Exception as e:  # noqa: BLE001
             error = e
-    if use_dist:
-        agree_on_status(error, group=group, device=getattr(bit_sets, "device", None))
-    elif error is not None:
+    if not use_dist and error is not None:
         raise error
     if not use_dist:
         if overflow:
@@ -392,7 +430,9 @@ def all_pairs_king_staged(ops, num_samples: int, tile: int, bit_sets,
                 "parameter.")
         recs = np.ascontiguousarray(local[:count].cpu().numpy()).view(np.uint32)
         return sort_results(recs.reshape(-1).view(KING_RESULT_DTYPE).copy()), steps
-    return gather_results(local, count, overflow, dst=dst, group=group), steps
+    # (the status of the pass rides in the gather's counts exchange)
+    return gather_results(local, count, overflow, dst=dst, group=group, error=error,
+                          device=getattr(bit_sets, "device", None)), steps
 
 
 class GpuStagedOps:

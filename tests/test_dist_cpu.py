@@ -272,6 +272,18 @@ def _failure_worker(rank, world, port, mode, out_path):
                     raise RuntimeError("injected kernel failure")
                 return local, 0, 0
             all_pairs_king(compute_tiles, 10, bits)
+        elif mode == "simple_folded":      # status inside the host-side gather's counts
+            def compute_tiles(b, begin, end):
+                if bad:
+                    raise RuntimeError("injected kernel failure")
+                return local, 0, 0
+            all_pairs_king(compute_tiles, 10, bits, device_counts=False)
+        elif mode == "device_folded":      # ... inside the device-side gather's header row
+            def compute_tiles(b, begin, end):
+                if bad:
+                    raise RuntimeError("injected kernel failure")
+                return local, torch.tensor([2, 0], dtype=torch.int32)
+            all_pairs_king(compute_tiles, 10, bits, device_counts=True, record_capacity=16)
         elif mode == "staged":
             class Ops:
                 def begin(self): pass
@@ -294,7 +306,7 @@ def _failure_worker(rank, world, port, mode, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["simple", "staged", "pipelined"])
+@pytest.mark.parametrize("mode", ["simple", "simple_folded", "device_folded", "staged", "pipelined"])
 @pytest.mark.timeout(120)
 def test_failure_on_one_rank_raises_on_all(tmp_path, mode):
     """SURVEY section 5 'per-rank error -> abort all ranks': an exception on one
