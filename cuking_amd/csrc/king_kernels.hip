@@ -160,7 +160,10 @@ __device__ __forceinline__ uint32_t spread8(uint32_t b) {
 // rows of the reference layout are words_per_sample x 8 bytes apart, so longer
 // runs mean fewer DRAM pages per byte), transposed through LDS, written 1 KiB
 // per k-row (64 consecutive samples).
-constexpr int kNibWords = 32;
+#ifndef CUKING_NIB_WORDS
+#define CUKING_NIB_WORDS 32  // (A/B: 16, 64)
+#endif
+constexpr int kNibWords = CUKING_NIB_WORDS;
 
 __global__ __launch_bounds__(256) void prepare_nibbles_kernel(
     const uint64_t *__restrict__ bits, uint32_t words_per_sample,
