@@ -109,6 +109,12 @@ struct cuking_ctx {
   // may overlap), split_wgs workgroups = one per CU.  0 = never split.
   uint32_t split_wgs = 0;
   std::vector<std::pair<hipStream_t, uint32_t *>> split_scratch;
+  // Filter variant (king_filter.hip): control words, candidate list and dense-
+  // quadrant list, one set per stream like the split scratch.  The two caps are
+  // options so that tests can force the dense and the list-full paths.
+  std::vector<std::pair<hipStream_t, uint8_t *>> filter_scratch;
+  uint32_t filter_quadrant_cap = kFilterQuadrantCap;
+  uint32_t filter_cand_cap = kFilterCandCap;
 
   // What the plane workspace holds: the block it was converted for and which
   // 64-sample plane tiles of it have been converted (cuking_compute_king_rect
@@ -118,6 +124,7 @@ struct cuking_ctx {
     cuking_submatrix sm = {0, 0, 0, 0};
     uint32_t words_per_sample = 0;
     int variant = -1;
+    uint32_t tile = 0;  // tile edge of the geometry (the context variant's)
     const uint64_t *bits = nullptr;
     // per 64 plane samples: 0 = not converted, 1 = converted (kernels that
     // read it, if any, all precede the tail of `ordered_on`), 2 = converted
@@ -163,8 +170,19 @@ int effective_variant(const cuking_ctx *ctx, uint32_t words_per_sample) {
   int v = ctx->variant;
   // (the four-product variant decides on an integer that matches the
   //  reference's float expression below 2^22 sites only)
-  if (v == kMfmaN4Variant && sites > kMfmaN4MaxSites) v = kMfmaVariant;
+  if ((v == kMfmaN4Variant || v == kMfmaFilterVariant) && sites > kMfmaN4MaxSites) v = kMfmaVariant;
   if (v == kMfmaVariant && sites > kMfmaMaxSites) v = 2;
+  return v;
+}
+
+// The shape everything about a call is laid out for: the kernel variant that
+// runs (layout, k padding) with the tile edge of the CONTEXT's variant, so that
+// tile indices, tile bounds and prepared ranges never depend on the width of
+// the bitset.  When the two differ (filter variant, 256-sample tiles, falling
+// back to a 128-tile kernel for a wide bitset) the kernel runs in quadrant mode.
+TiledVariant plan_variant(const cuking_ctx *ctx, uint32_t words_per_sample) {
+  TiledVariant v = tiled_variant(effective_variant(ctx, words_per_sample));
+  v.tile = tiled_variant(ctx->variant).tile;
   return v;
 }
 
@@ -277,6 +295,60 @@ cuking_status split_scratch_for(cuking_ctx *ctx, hipStream_t stream,
   return CUKING_OK;
 }
 
+// Filter scratch of `stream` (allocated on first use; the control words are
+// zeroed by every launch chunk), or nothing when the context's variant is not
+// the filter variant.  Fills the filter fields of `a`.
+cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const PlaneGeometry &geo,
+                                 TiledArgs *a) {
+  a->sample_stats = nullptr;
+  a->filter_ctrl = nullptr;
+  a->cand_list = nullptr;
+  a->dense_list = nullptr;
+  a->cand_cap = a->dense_cap = a->quadrant_cap = 0;
+  if (ctx->variant != kMfmaFilterVariant) return CUKING_OK;
+  uint8_t *base = nullptr;
+  for (auto &e : ctx->filter_scratch)
+    if (e.first == stream) base = e.second;
+  if (base == nullptr) {
+    if (ctx->filter_scratch.size() >= 8) {  // (see split_scratch_for)
+      ++ctx->host_syncs;
+      HIP_TRY(hipDeviceSynchronize());
+      for (auto &e : ctx->filter_scratch) (void)hipFree(e.second);
+      ctx->filter_scratch.clear();
+    }
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base), filter_scratch_bytes()));
+    ++ctx->workspace_allocations;
+    ctx->filter_scratch.emplace_back(stream, base);
+  }
+  a->sample_stats = plane_stats(ctx->planes, geo);
+  a->filter_ctrl = reinterpret_cast<uint32_t *>(base);
+  a->cand_list = reinterpret_cast<uint2 *>(base + kFilterCtrlBytes);
+  a->cand_cap = ctx->filter_cand_cap;
+  a->quadrant_cap = ctx->filter_quadrant_cap;
+  a->dense_list = a->cand_list + kFilterCandCap;
+  a->dense_cap = kFilterChunkTiles * 4;
+  return CUKING_OK;
+}
+
+// Enqueues `num_tiles` tiles of the planned geometry: as they are when the
+// kernel's tile edge is the geometry's, as four quadrants each otherwise.
+hipError_t launch_planned(const cuking_ctx *ctx, uint32_t words_per_sample, bool full,
+                          TiledArgs a, uint64_t num_tiles, hipStream_t stream) {
+  const int kv = effective_variant(ctx, words_per_sample);
+  a.quad = 0;
+  a.tile_list = nullptr;
+  a.tile_list_count = nullptr;
+  a.tile_list_cap = 0;
+  if (tiled_variant(kv).tile != tiled_variant(ctx->variant).tile) {
+    // (only the filter variant's 256-sample geometry over a 128-tile kernel)
+    if (tiled_variant(kv).tile * 2 != tiled_variant(ctx->variant).tile) return hipErrorInvalidValue;
+    a.quad = 1;
+    a.tile_begin *= 4;
+    num_tiles *= 4;
+  }
+  return launch_tiled(kv, full, a, num_tiles, stream);
+}
+
 // A pair kernel that reads the workspace has been enqueued on `stream`.
 void note_reader(cuking_ctx *ctx, hipStream_t stream) {
   for (auto &r : ctx->readers)
@@ -330,11 +402,11 @@ void mark_read(cuking_ctx *ctx, uint32_t begin, uint32_t end) {
 }
 
 bool same_block(const cuking_ctx::Prepared &p, const cuking_submatrix &sm,
-                uint32_t words_per_sample, int variant, const uint64_t *bits) {
+                uint32_t words_per_sample, int variant, uint32_t tile, const uint64_t *bits) {
   return p.valid && p.sm.i_begin == sm.i_begin && p.sm.i_end == sm.i_end &&
          p.sm.j_begin == sm.j_begin && p.sm.j_end == sm.j_end &&
          p.words_per_sample == words_per_sample && p.variant == variant &&
-         p.bits == bits;
+         p.tile == tile && p.bits == bits;
 }
 
 // Makes the plane workspace at least `need` bytes and the band prefix at least
@@ -393,7 +465,7 @@ cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
                       TileSpace *tiles_out, uint32_t s_tile_begin = 0,
                       uint32_t s_tile_end = 0xFFFFFFFFu) {
   const int variant = effective_variant(ctx, words_per_sample);
-  const TiledVariant &v = tiled_variant(variant);
+  const TiledVariant v = plan_variant(ctx, words_per_sample);
   const PlaneGeometry geo = make_geometry(sm, words_per_sample, v);
   const TileSpace tiles = make_tiles(geo, v, ctx->band_rows);
   *geo_out = geo;
@@ -410,7 +482,7 @@ cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
   const uint32_t t_end = s_tile_end < all_tiles ? s_tile_end : all_tiles;
   cuking_ctx::Prepared &pr = ctx->prepared;
   const bool new_prefix = !same_tile_space(ctx->prefix_for, tiles);
-  const bool same = same_block(pr, sm, words_per_sample, variant, d_bit_sets);
+  const bool same = same_block(pr, sm, words_per_sample, variant, v.tile, d_bit_sets);
   if (ctx->reuse_prepared && same && !new_prefix) {
     // The host has promised that the bitset behind this pointer is unchanged
     // since it was converted (cuking_invalidate otherwise): nothing to do when
@@ -434,6 +506,7 @@ cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
     pr.sm = sm;
     pr.words_per_sample = words_per_sample;
     pr.variant = variant;
+    pr.tile = v.tile;
     pr.bits = d_bit_sets;
     pr.tiles.assign(all_tiles, 0);
   }
@@ -509,12 +582,14 @@ cuking_status run_tiled(cuking_ctx *ctx, const cuking_submatrix &sm,
   a.dyn_wgs = 0;
   st = split_scratch_for(ctx, stream, &a.split_scratch, &a.split_counters);
   if (st != CUKING_OK) return st;
+  st = filter_scratch_for(ctx, stream, geo, &a);
+  if (st != CUKING_OK) return st;
 
   EventPair *ev = nullptr;
   if (ctx->timing) HIP_TRY(ctx->king_timer.begin(stream, &ev));
-  HIP_TRY(launch_tiled(effective_variant(ctx, words_per_sample),
-                       use_full_counts(ctx, kin_threshold, d_counts != nullptr, words_per_sample), a,
-                       tile_end - tile_begin, stream));
+  HIP_TRY(launch_planned(ctx, words_per_sample,
+                         use_full_counts(ctx, kin_threshold, d_counts != nullptr, words_per_sample), a,
+                         tile_end - tile_begin, stream));
   note_reader(ctx, stream);
   mark_read(ctx, 0, 0xFFFFFFFFu);
   if (ev) HIP_TRY(hipEventRecord(ev->stop, stream));
@@ -596,6 +671,7 @@ void cuking_ctx_destroy(cuking_ctx *ctx) {
   if (ctx->planes) (void)hipFree(ctx->planes);
   if (ctx->band_prefix) (void)hipFree(ctx->band_prefix);
   for (auto &e : ctx->split_scratch) (void)hipFree(e.second);
+  for (auto &e : ctx->filter_scratch) (void)hipFree(e.second);
   for (auto &r : ctx->readers)
     if (r.second) (void)hipEventDestroy(r.second);
   ctx->king_timer.destroy();
@@ -661,6 +737,18 @@ cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
     if (value < -1 || value > 1)
       return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "counts_mode outside [-1, 1]");
     ctx->counts_mode = (int)value;
+    return CUKING_OK;
+  }
+  if (strcmp(key, "filter_quadrant_cap") == 0) {  // tests: 0 sends every quadrant with a candidate to the exact kernel
+    if (value < 0 || value > 16384)
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "filter_quadrant_cap outside [0, 16384]");
+    ctx->filter_quadrant_cap = (uint32_t)value;
+    return CUKING_OK;
+  }
+  if (strcmp(key, "filter_cand_cap") == 0) {  // tests: a short candidate list
+    if (value < 0 || value > (int64_t)kFilterCandCap)
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "filter_cand_cap outside [0, %u]", kFilterCandCap);
+    ctx->filter_cand_cap = (uint32_t)value;
     return CUKING_OK;
   }
   if (strcmp(key, "reuse_prepared") == 0) {
@@ -887,6 +975,8 @@ cuking_status cuking_ctx_get_option(const cuking_ctx *ctx, const char *key,
   else if (strcmp(key, "xcd_swizzle") == 0) *value = ctx->xcd_swizzle;
   else if (strcmp(key, "dyn_tail_tiles") == 0) *value = ctx->dyn_tail_tiles;
   else if (strcmp(key, "reuse_prepared") == 0) *value = ctx->reuse_prepared ? 1 : 0;
+  else if (strcmp(key, "filter_quadrant_cap") == 0) *value = ctx->filter_quadrant_cap;
+  else if (strcmp(key, "filter_cand_cap") == 0) *value = ctx->filter_cand_cap;
   else if (strcmp(key, "workspace_allocations") == 0) *value = (int64_t)ctx->workspace_allocations;
   else if (strcmp(key, "host_syncs") == 0) *value = (int64_t)ctx->host_syncs;
   else if (strcmp(key, "conversions_skipped") == 0) *value = (int64_t)ctx->conversions_skipped;
@@ -983,7 +1073,7 @@ cuking_status cuking_prepare_samples(cuking_ctx *ctx, const cuking_submatrix *sm
   if (!sm_is_diag(*sm))
     return cuking_fail(CUKING_ERR_INVALID_ARGUMENT,
                 "staged preparation needs a diagonal block (rows == columns)");
-  const uint32_t tile = tiled_variant(effective_variant(ctx, words_per_sample)).tile;
+  const uint32_t tile = plan_variant(ctx, words_per_sample).tile;
   uint32_t t0, t1;
   st = tile_span(*sm, tile, sample_begin, sample_end, "sample", &t0, &t1);
   if (st != CUKING_OK) return st;
@@ -1010,7 +1100,7 @@ cuking_status cuking_compute_king_rect(
                 "rectangle launches need a diagonal block (rows == columns)");
   if (!d_result_index || !d_result_overflow || (max_results && !d_results))
     return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null result pointer");
-  const TiledVariant &v = tiled_variant(effective_variant(ctx, words_per_sample));
+  const TiledVariant v = plan_variant(ctx, words_per_sample);
   const PlaneGeometry geo = make_geometry(*sm, words_per_sample, v);
   // Rectangles of a diagonal block contain slots below the diagonal that leave
   // at once; one contiguous chunk of the enumeration per XCD then leaves some
@@ -1022,7 +1112,7 @@ cuking_status cuking_compute_king_rect(
   const size_t need = plane_bytes(geo, v.layout);
   const int variant = effective_variant(ctx, words_per_sample);
   if (ctx->planes == nullptr || ctx->planes_bytes < need ||
-      !same_block(ctx->prepared, *sm, words_per_sample, variant, d_bit_sets))
+      !same_block(ctx->prepared, *sm, words_per_sample, variant, v.tile, d_bit_sets))
     return cuking_fail(CUKING_ERR_FAILED_PRECONDITION,
                 "cuking_prepare_samples() has not been called for this block "
                 "(or the workspace has been converted for another one since)");
@@ -1090,11 +1180,13 @@ cuking_status cuking_compute_king_rect(
   a.dyn_wgs = 0;
   st = split_scratch_for(ctx, (hipStream_t)stream, &a.split_scratch, &a.split_counters);
   if (st != CUKING_OK) return st;
+  st = filter_scratch_for(ctx, (hipStream_t)stream, geo, &a);
+  if (st != CUKING_OK) return st;
   EventPair *ev = nullptr;
   if (ctx->timing) HIP_TRY(ctx->king_timer.begin((hipStream_t)stream, &ev));
-  HIP_TRY(launch_tiled(effective_variant(ctx, words_per_sample),
-                       use_full_counts(ctx, kin_threshold, false, words_per_sample), a,
-                       (uint64_t)n_rows * (c1 - c0), (hipStream_t)stream));
+  HIP_TRY(launch_planned(ctx, words_per_sample,
+                         use_full_counts(ctx, kin_threshold, false, words_per_sample), a,
+                         (uint64_t)n_rows * (c1 - c0), (hipStream_t)stream));
   note_reader(ctx, (hipStream_t)stream);
   {
     const uint32_t per = v.tile / 64;
@@ -1115,8 +1207,7 @@ cuking_status cuking_ctx_reserve(cuking_ctx *ctx, const cuking_submatrix *sm,
   if (num_streams != 0 && streams == nullptr)
     return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null stream list");
   if (sm_num_rows(*sm) == 0 || sm_num_cols(*sm) == 0) return CUKING_OK;
-  const int variant = effective_variant(ctx, words_per_sample);
-  const TiledVariant &v = tiled_variant(variant);
+  const TiledVariant v = plan_variant(ctx, words_per_sample);
   const PlaneGeometry geo = make_geometry(*sm, words_per_sample, v);
   const TileSpace tiles = make_tiles(geo, v, ctx->band_rows);
   st = ensure_workspace(ctx, plane_bytes(geo, v.layout), (size_t)tiles.num_bands() + 1);
@@ -1149,9 +1240,26 @@ cuking_status cuking_ctx_reserve(cuking_ctx *ctx, const cuking_submatrix *sm,
       ctx->split_scratch.clear();
     }
   }
+  if (ctx->variant == kMfmaFilterVariant) {
+    size_t missing = 0;
+    for (size_t k = 0; k < num_streams; ++k) {
+      bool have = false;
+      for (auto &e : ctx->filter_scratch) have = have || e.first == (hipStream_t)streams[k];
+      missing += have ? 0 : 1;
+    }
+    if (missing != 0 && ctx->filter_scratch.size() + missing > 8) {
+      ++ctx->host_syncs;
+      HIP_TRY(hipDeviceSynchronize());
+      for (auto &e : ctx->filter_scratch) (void)hipFree(e.second);
+      ctx->filter_scratch.clear();
+    }
+  }
   for (size_t k = 0; k < num_streams; ++k) {
     uint32_t *scratch, *counters;
     st = split_scratch_for(ctx, (hipStream_t)streams[k], &scratch, &counters);
+    if (st != CUKING_OK) return st;
+    TiledArgs unused;
+    st = filter_scratch_for(ctx, (hipStream_t)streams[k], geo, &unused);
     if (st != CUKING_OK) return st;
   }
   return CUKING_OK;

@@ -50,6 +50,9 @@ namespace cuking {
 constexpr uint32_t kLayoutWord = 0;
 constexpr uint32_t kLayoutQuad = 1;
 constexpr uint32_t kLayoutNibble = 2;
+// ... plus, behind the het-only copy, one float2 per stored sample for the
+// filter kernel (king_filter.hip): (homozygous - missing site count, het count).
+constexpr uint32_t kLayoutNibbleStats = 3;
 
 struct PlaneGeometry {
   uint32_t num_rows, num_cols;        // block shape in samples
@@ -164,6 +167,29 @@ struct TiledArgs {
   // On entry to a launch function dyn_tiles is the context's threshold: launches
   // of at least that many tiles get a dynamic tail (0 = never).
   uint32_t dyn_tiles, dyn_wgs;
+  // Quadrant mode (quad != 0): the tile space above is one of 256-sample tiles
+  // (the filter variant's geometry) and the launch enumerates their four
+  // 128-sample quadrants: unit t = quadrant t % 4 (row half t / 2 % 2, column
+  // half t % 2) of tile t / 4.  Lets every 128-tile kernel serve a context whose
+  // tile indices, tile bounds and prepared ranges are in 256-sample units.
+  uint32_t quad;
+  // Tile-list mode (tile_list != nullptr; matrix-core kernels): the 128-sample
+  // tiles to compute are the first min(*tile_list_count, tile_list_cap) entries
+  // (x = tile row, y = tile column) of a device list written by an earlier
+  // kernel of the stream; workgroup b takes entries b, b + grid, ...
+  const uint2 *tile_list;
+  const uint32_t *tile_list_count;
+  uint32_t tile_list_cap;
+  // Filter variant (king_filter.hip): per-sample statistics, control words
+  // (candidate count, dense-quadrant count), the candidate pairs and the
+  // quadrants handed to the exact kernel instead.
+  const float2 *sample_stats;
+  uint32_t *filter_ctrl;
+  uint2 *cand_list;
+  uint32_t cand_cap;       // entries of cand_list
+  uint32_t quadrant_cap;   // candidates per quadrant beyond which it is "dense"
+  uint2 *dense_list;
+  uint32_t dense_cap;
 };
 
 // Bytes of the plane workspace for a geometry.
@@ -172,7 +198,13 @@ __host__ __device__ inline size_t plane_bytes(const PlaneGeometry &g,
   // word layout: 16 B per 32-site word and sample; quad layout: 2 x 16 B per
   // four words and sample; nibble layout: 16 B per 32 sites and sample.
   const size_t base = (size_t)g.k_words * g.s_stride * (layout == kLayoutQuad ? 8 : 16);
-  return layout == kLayoutNibble ? base + base / 4 : base;  // + the het-only copy
+  if (layout == kLayoutNibble) return base + base / 4;  // + the het-only copy
+  if (layout == kLayoutNibbleStats) return base + base / 4 + (size_t)g.s_stride * sizeof(float2);
+  return base;
+}
+// Where the per-sample statistics of kLayoutNibbleStats start.
+__host__ __device__ inline const float2 *plane_stats(const uint4 *planes, const PlaneGeometry &g) {
+  return reinterpret_cast<const float2 *>(planes + (size_t)g.k_words * g.s_stride * 5 / 4);
 }
 
 // One compiled shape of the tiled kernel.
@@ -190,9 +222,9 @@ struct TiledVariant {
 constexpr uint32_t kMfmaMaxSites = 1u << 24;
 
 #ifdef CUKING_TUNING
-constexpr int kNumTiledVariants = 13;  // + timing-only experiments
+constexpr int kNumTiledVariants = 14;  // + timing-only experiments
 #else
-constexpr int kNumTiledVariants = 7;
+constexpr int kNumTiledVariants = 8;
 #endif
 constexpr int kMfmaVariant = 5;    // five plane products, quad layout
 constexpr int kMfmaN4Variant = 6;  // four plane products, nibble layout (king_mfma.hip)
@@ -204,7 +236,24 @@ constexpr uint32_t kMfmaN4MaxSites = 1u << 22;
 constexpr int kMfmaN4Stages = 5;
 constexpr uint32_t kMfmaN4LdsBytes = kMfmaN4Stages * 2 * 2 * 4 * 128 * 16;  // 5 x 32 KiB
 static_assert(kMfmaN4LdsBytes <= 160 * 1024, "LDS of one CU");
-inline bool is_mfma_variant(int v) { return v == kMfmaVariant || v == kMfmaN4Variant; }
+// One plane product T_i.T_j per pair as a rigorous upper bound on kinship, exact
+// recount of the few pairs it lets through (king_filter.hip); 256-sample tiles.
+constexpr int kMfmaFilterVariant = 7;
+constexpr uint32_t kFilterTile = 256;
+constexpr uint32_t kFilterLdsBytes = 5 * 2 * 2 * 2 * 256 * 16;  // 5 x 32 KiB
+static_assert(kFilterLdsBytes <= 160 * 1024, "LDS of one CU");
+// Per launch chunk: at most this many 256-tiles (bounds the dense-quadrant list).
+constexpr uint32_t kFilterChunkTiles = 1u << 16;
+constexpr uint32_t kFilterCandCap = 1u << 20;      // candidate pairs per chunk
+constexpr uint32_t kFilterQuadrantCap = 1024;      // candidates per 128 x 128 quadrant
+constexpr size_t kFilterCtrlBytes = 256;
+inline size_t filter_scratch_bytes() {
+  return kFilterCtrlBytes + (size_t)kFilterCandCap * sizeof(uint2) +
+         (size_t)kFilterChunkTiles * 4 * sizeof(uint2);
+}
+inline bool is_mfma_variant(int v) {
+  return v == kMfmaVariant || v == kMfmaN4Variant || v == kMfmaFilterVariant;
+}
 #ifndef CUKING_MFMA_STAGES
 #define CUKING_MFMA_STAGES 6
 #endif
@@ -223,6 +272,15 @@ hipError_t launch_tiled(int variant, bool full, const TiledArgs &args,
 // The matrix-core kernel (king_mfma.hip); reached through launch_tiled.
 hipError_t launch_mfma(bool full, bool nibble, const TiledArgs &args, uint64_t num_tiles,
                        uint32_t lds_bytes, hipStream_t stream);
+// The four-product kernel, lean form, over args.tile_list with `grid` workgroups.
+hipError_t launch_mfma_list(const TiledArgs &args, uint32_t grid, hipStream_t stream);
+// The filter variant (king_filter.hip): num_tiles 256-sample tiles from
+// args.tile_begin; needs args.filter_ctrl etc. (king_abi.hip: filter scratch).
+hipError_t launch_filter(const TiledArgs &args, uint64_t num_tiles, hipStream_t stream);
+// Statistics of plane samples [s_begin, s_end) of a kLayoutNibbleStats workspace.
+hipError_t launch_sample_stats(const uint64_t *d_bit_sets, uint32_t words_per_sample,
+                               const PlaneGeometry &geo, uint4 *d_planes, uint32_t s_begin,
+                               uint32_t s_end, hipStream_t stream);
 // Bytes of split scratch (counters, then slabs) for `wgs` workgroups, and of
 // the counter part alone (the only part that must start out zero).
 size_t mfma_split_scratch_bytes(uint32_t wgs);

@@ -98,8 +98,27 @@ __device__ __forceinline__ uint32_t wave_hom_hom_count(
 // Returns false when there is nothing to do (rectangle mode, below the
 // diagonal of a diagonal block): the whole workgroup must then leave before
 // any barrier.
+__device__ __forceinline__ bool decode_tile_space(const TiledArgs &a, uint64_t t,
+                                                  uint32_t *tr, uint32_t *tc);
 __device__ __forceinline__ bool decode_tile(const TiledArgs &a, uint64_t t,
                                             uint32_t *tr, uint32_t *tc) {
+  if (a.tile_list != nullptr) {  // tile-list mode (king_common.h)
+    const uint2 e = a.tile_list[t];
+    *tr = e.x;
+    *tc = e.y;
+    return true;
+  }
+  if (a.quad == 0) return decode_tile_space(a, t, tr, tc);
+  // Quadrant mode: quadrant t % 4 of the 256-sample tile t / 4.
+  uint32_t r, c;
+  if (!decode_tile_space(a, t >> 2, &r, &c)) return false;
+  *tr = 2 * r + (uint32_t)((t >> 1) & 1);
+  *tc = 2 * c + (uint32_t)(t & 1);
+  // (a diagonal tile's lower-left quadrant holds no pair with i < j)
+  return !(a.tiles.diag && *tc < *tr);
+}
+__device__ __forceinline__ bool decode_tile_space(const TiledArgs &a, uint64_t t,
+                                                  uint32_t *tr, uint32_t *tc) {
   if (a.rect_rows != 0) {
     // Rectangle mode: bands of band_rows rows of the rectangle, column-major
     // inside a band (same locality as the whole-block enumeration).  Only the

@@ -1,0 +1,529 @@
+// The filter variant of the KING pair kernel on the gfx950 matrix cores: ONE
+// plane product per pair and site instead of four, as a rigorous upper bound on
+// kinship, and the exact sums only for the pairs the bound lets through.
+//
+// With g = -1 / 0 / +1 for hom-ref / het / hom-alt, the reference's numerator
+// (cuking.cu:289-294) is -X with
+//     X = het_i + het_j - 2 both_het + 4 opposing_hom
+//       = sum over the sites defined in both samples of (g_i - g_j)^2
+//       = Y_i.D_j + D_i.Y_j - 2 T_i.T_j
+// (Y homozygous and defined, D defined, T = R - A; king_mfma.hip "Four
+// products").  Y_i.D_j = |Y_i| - Y_i.M_j >= |Y_i| - |M_j| (M missing), and
+// het_i = H_i.D_j <= |H_i|, so with the per-sample counts u = |Y| - |M| and |H|
+//     X >= u_i + u_j - 2 q,   q = T_i.T_j,
+//     kin = 1/2 - X / (4 min(het_i, het_j)) <= 1/2 - (u_i + u_j - 2 q) / (4 min(|H_i|, |H_j|)).
+// A pair can only pass `kin > threshold` (0 < threshold < 1/2) when
+//     u_i + u_j - 2 q < (2 - 4 threshold) min(|H_i|, |H_j|) + margin,
+// the margin (8 sites) covering the float32 roundings of the reference's divide
+// and add and of this test (launch_filter's callers keep bitsets below 2^22
+// sites, where every term is an exact float).  The slack of the bound is the
+// missingness: |M_i| + |M_j| sites, i.e. ~0.01 in kinship at a 1 % missing rate
+// with a third of the sites heterozygous; unrelated pairs sit around 0, so at
+// the usual thresholds (>= 0.04) next to nothing but real records gets through.
+//
+// Pipeline per launch chunk (<= kFilterChunkTiles tiles of 256 x 256 pairs):
+//   1. king_filter_kernel: q for every pair on the matrix cores (T is the
+//      nibble layout's bits 2-3, +-2.0 in fp4: one v_and per fragment dword, the
+//      accumulators carry 4 q), the test above per pair; candidates are appended
+//      to a list, or, when a 128 x 128 quadrant has more than quadrant_cap of
+//      them (or the list is full), the quadrant is put on the dense list.
+//   2. king_refine_kernel: one wavefront per candidate, the reference's own six
+//      sums straight from the bitset (king_kernels.hip stream kernel), exact
+//      kinship, record.
+//   3. the four-product kernel (king_mfma.hip, tile-list mode) over the dense
+//      quadrants -- nothing, on ordinary cohorts.
+// Same records as every other variant, whatever the data: the bound only
+// decides WHO computes a pair exactly.
+//
+// Workgroup = 256 x 256 pairs, 4 wavefronts of 128 x 128 = 4 x 4 MFMA blocks (256
+// accumulator registers), k-step = 128 sites = 2 slices of 64, 5 LDS stages of
+// 32 KiB by LDS-DMA.  Per slice and wavefront: 16 MFMAs, 8 ds_read_b128, 32
+// v_and, 4 requests of 1 KiB.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "king_common.h"
+#include "king_device.h"
+
+// The LDS-DMA statements below write M0 and say so in their clobber lists.
+#pragma clang diagnostic ignored "-Winline-asm"
+
+namespace cuking {
+
+namespace {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int kT = (int)kFilterTile;
+constexpr int kStages = 5;
+constexpr int kSliceU4 = kT;                     // one (side, k-half, slice): 256 samples
+constexpr int kStageU4 = 2 * 2 * 2 * kSliceU4;   // uint4 per stage (32 KiB)
+static_assert(kStages * kStageU4 * 16 == (int)kFilterLdsBytes, "LDS size");
+constexpr int vmcnt_imm(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
+constexpr uint32_t kNoPair = 0xFFFFFFFFu;
+
+// Which stored sample of the reference bitset plane sample `ps` is (the same
+// mapping as the prepare kernels), or kNoPair for padding.
+__device__ __forceinline__ uint32_t source_sample(const PlaneGeometry &geo, uint32_t ps) {
+  if (geo.diag || ps < geo.rows_padded) return ps < geo.num_rows ? ps : kNoPair;
+  const uint32_t c = ps - geo.col_base;
+  return c < geo.num_cols ? geo.num_rows + c : kNoPair;
+}
+
+// One wavefront per plane sample: (|Y| - |M|, |H|) as floats (exact below 2^24
+// sites).  Padding sites of the last word are missing (cuking.cu:513-523) and
+// count as such; padding samples get (0, 0).
+__global__ __launch_bounds__(256) void sample_stats_kernel(
+    const uint64_t *__restrict__ bits, uint32_t words_per_sample, PlaneGeometry geo,
+    float2 *__restrict__ stats, uint32_t s_begin, uint32_t s_end) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t ps = s_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ps >= s_end) return;  // whole wavefront
+  const uint32_t src = source_sample(geo, ps);
+  int32_t yc = 0, mc = 0, hc = 0;
+  if (src != kNoPair) {
+    const uint32_t n = words_per_sample / 2;
+    const uint64_t *het = bits + (uint64_t)src * words_per_sample;
+    const uint64_t *hom = het + n;
+    for (uint32_t w = lane; w < n; w += 64) {
+      const uint64_t h = het[w], v = hom[w];
+      yc += __popcll(~h);      // homozygous and defined (missing has the het bit set)
+      mc += __popcll(h & v);   // missing
+      hc += __popcll(h & ~v);  // het
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      yc += __shfl_xor(yc, off);
+      mc += __shfl_xor(mc, off);
+      hc += __shfl_xor(hc, off);
+    }
+  }
+  if (lane == 0) stats[ps] = make_float2((float)(yc - mc), (float)hc);
+}
+
+__device__ __forceinline__ v16f mma(const v8i a, const v8i b, const v16f c) {
+  // scale operands 0: the unscaled instruction
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4 /* fp4 */, 4, 0, 0, 0, 0);
+}
+
+__device__ __forceinline__ v8i tfrag(const uint4 w, uint32_t mask) {
+  v8i r = {0, 0, 0, 0, 0, 0, 0, 0};
+  r[0] = (int)(w.x & mask);
+  r[1] = (int)(w.y & mask);
+  r[2] = (int)(w.z & mask);
+  r[3] = (int)(w.w & mask);
+  return r;
+}
+
+// One LDS-DMA request: lane l's 16 bytes of SRC + OFF land at DST + OFF + 16 l
+// (the immediate offset moves source and destination alike).
+#define F_ISSUE(SRC, DST, OFF)                                                 \
+  asm volatile("s_mov_b32 m0, %0\n\t"                                          \
+               "s_nop 0\n\t"                                                   \
+               "global_load_lds_dwordx4 %1, %2 offset:" #OFF                   \
+               :                                                               \
+               : "s"(DST), "v"(lane16), "s"(SRC)                               \
+               : "memory", "m0")
+
+__global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) {
+  extern __shared__ uint4 lds[];  // [kStages][side][k-half][slice][256]
+
+  uint32_t bid = blockIdx.x;
+  if (a.xcd_chunk == 1) {
+    // patches of 32 consecutive tiles dealt round-robin to the XCDs (king_common.h)
+    const uint32_t x = bid & 7, j = bid >> 3;
+    bid = (((j >> 5) * 8 + x) << 5) + (j & 31);
+    if (bid >= a.launch_tiles) return;  // padding (uniform)
+  }
+  bid = __builtin_amdgcn_readfirstlane(bid);
+  uint32_t tr, tc;
+  if (!decode_tile_space(a, a.tile_begin + bid, &tr, &tc)) return;  // uniform
+  tr = __builtin_amdgcn_readfirstlane(tr);
+  tc = __builtin_amdgcn_readfirstlane(tc);
+
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t wy = wave >> 1, wx = wave & 1;  // the wavefront's quadrant
+  const uint32_t g = lane >> 5;                  // k-half of the MFMA operand
+  const uint32_t lr = lane & 31;                 // row / column inside a block
+  uint32_t lane16 = lane * 16;
+  const uint32_t s_stride = a.geo.s_stride;
+  const uint32_t num_steps = a.geo.k_words / 4;  // k-steps of 128 sites
+  const uint4 *g_rows = a.planes + (uint64_t)tr * kT;
+  const uint4 *g_cols = a.planes + a.geo.col_base + (uint64_t)tc * kT;
+
+  uint32_t mT;
+  asm volatile("s_mov_b32 %0, 0xcccccccc" : "=s"(mT));
+
+  // LDS-DMA: wavefront (side, k-half) fetches that quarter of a stage: 2 slices
+  // x 4 runs of 64 samples, 1 KiB each.  Slice c of k-step s, k-half h is group
+  // 4 s + 2 h + c of the nibble layout (the order of the sites inside k does not
+  // matter as long as rows and columns agree).
+  const uint32_t dma_side = wave >> 1, dma_h = wave & 1;
+  const uint32_t row_bytes = s_stride * 16;  // one group of the layout
+  const char *const g_wave = reinterpret_cast<const char *>(
+      (dma_side ? g_cols : g_rows) + (uint64_t)(2 * dma_h) * s_stride);
+  const uint32_t l_wave = (uint32_t)(uintptr_t)(lds_void_ptr)(
+      lds + ((dma_side * 2 + dma_h) * 2) * kSliceU4);
+  struct Addr { const char *src; uint32_t dst; };  // of slice 0; slice 1: + row_bytes, + 4 KiB
+  auto addr_of = [&](uint32_t step, uint32_t buf) {
+    Addr pa;
+    if (step >= num_steps) step = num_steps - 1;  // clamped repeats (see king_mfma.hip)
+    pa.src = g_wave + (uint64_t)step * 4 * row_bytes;
+    pa.dst = l_wave + buf * (kStageU4 * 16);
+    asm volatile("" : "+s"(pa.src), "+s"(pa.dst));
+    return pa;
+  };
+  const uint32_t kstep_bytes = 4 * row_bytes;
+  auto addr_next = [&](const Addr &cur, uint32_t step, uint32_t buf) {
+    Addr pa;
+    const uint32_t adv = step < num_steps ? kstep_bytes : 0u;
+    pa.src = cur.src + adv;
+    pa.dst = l_wave + buf * (kStageU4 * 16);
+    asm volatile("" : "+s"(pa.src), "+s"(pa.dst));
+    return pa;
+  };
+  // The four requests of slice c of the stage `pa` names.
+#define F_ISSUE4(PA, C)                                                        \
+  {                                                                            \
+    const char *src_ = (PA).src + (C) * row_bytes;                             \
+    const uint32_t dst_ = (PA).dst + (C) * (kSliceU4 * 16);                    \
+    F_ISSUE(src_, dst_, 0);                                                    \
+    F_ISSUE(src_, dst_, 1024);                                                 \
+    F_ISSUE(src_, dst_, 2048);                                                 \
+    F_ISSUE(src_, dst_, 3072);                                                 \
+  }
+
+  v16f acc[4][4];
+#pragma unroll
+  for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
+
+  // Stages 0 .. 3 requested, stage 0 landed.
+#pragma unroll
+  for (int st = 0; st < kStages - 1; ++st) {
+    const Addr p0 = addr_of(st, st);
+    F_ISSUE4(p0, 0)
+    F_ISSUE4(p0, 1)
+  }
+  __builtin_amdgcn_s_waitcnt(vmcnt_imm(3 * 8));
+  __syncthreads();
+
+  // This lane's operand words inside a stage (uint4 units).
+  uint32_t row_off = ((0 * 2 + g) * 2) * kSliceU4 + wy * 128 + lr;
+  uint32_t col_off = ((1 * 2 + g) * 2) * kSliceU4 + wx * 128 + lr;
+  asm volatile("" : "+v"(row_off), "+v"(col_off), "+v"(lane16));
+  v8i FA[2][4], FB[2][4];  // T fragments [slice parity][block]
+  uint4 RAW[8];            // the next slice's words: rows 0-3, columns 4-7
+#define F_READ(K, BUF, C)                                                      \
+  RAW[K] = lds[(BUF) * kStageU4 + ((K) < 4 ? row_off : col_off) + (C) * kSliceU4 + ((K) & 3) * 32];
+// (plain ANDs: nothing but data orders them against the MFMAs, and left alone
+// the compiler builds every fragment right behind its LDS read, i.e. waits for
+// the read it has just issued.  The empty asm statements tie a build to the
+// place it is written in: not above the pin of its input, not below the pin of
+// its result -- as in king_mfma.hip.)
+#define F_PIN4(W) asm volatile("" : "+v"((W).x), "+v"((W).y), "+v"((W).z), "+v"((W).w));
+#define F_PINF(F) asm volatile("" : "+v"((F)[0]), "+v"((F)[1]), "+v"((F)[2]), "+v"((F)[3]));
+#define F_BUILD(NXT, K)                                                        \
+  F_PIN4(RAW[K])                                                               \
+  if ((K) < 4) {                                                               \
+    FA[NXT][(K) & 3] = tfrag(RAW[K], mT);                                      \
+    F_PINF(FA[NXT][(K) & 3])                                                   \
+  } else {                                                                     \
+    FB[NXT][(K) & 3] = tfrag(RAW[K], mT);                                      \
+    F_PINF(FB[NXT][(K) & 3])                                                   \
+  }
+#define F_MMA(CUR, BI, BJ) acc[BI][BJ] = mma(FA[CUR][BI], FB[CUR][BJ], acc[BI][BJ]);
+  // One slice of 64 sites.  CUR / NXT: fragment sets of this and the next slice;
+  // (RBUF, RC): stage buffer and slice the next slice's words are read from;
+  // SYNC: stage hand-over first (that read is the first of a new stage);
+  // (PA, DC): the four requests that go out during this slice.
+  // First half: block rows 0-1 with the reads and the requests in the MFMA gaps;
+  // second half: block rows 2-3 with the fragment builds of the next slice.
+#define F_SLICE(CUR, NXT, RBUF, RC, SYNC, PA, DC)                              \
+  {                                                                            \
+    if (SYNC) {                                                                \
+      __builtin_amdgcn_s_waitcnt(vmcnt_imm(2 * 8 + 4));                        \
+      __syncthreads();                                                         \
+    }                                                                          \
+    const char *src_ = (PA).src + (DC) * row_bytes;                            \
+    const uint32_t dst_ = (PA).dst + (DC) * (kSliceU4 * 16);                   \
+    F_READ(0, RBUF, RC) F_READ(1, RBUF, RC)                                    \
+    F_ISSUE(src_, dst_, 0);                                                    \
+    F_MMA(CUR, 0, 0) F_MMA(CUR, 0, 1)                                          \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    F_READ(2, RBUF, RC) F_READ(3, RBUF, RC)                                    \
+    F_ISSUE(src_, dst_, 1024);                                                 \
+    F_MMA(CUR, 0, 2) F_MMA(CUR, 0, 3)                                          \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    F_READ(4, RBUF, RC) F_READ(5, RBUF, RC)                                    \
+    F_ISSUE(src_, dst_, 2048);                                                 \
+    F_MMA(CUR, 1, 0) F_MMA(CUR, 1, 1)                                          \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    F_READ(6, RBUF, RC) F_READ(7, RBUF, RC)                                    \
+    F_ISSUE(src_, dst_, 3072);                                                 \
+    F_MMA(CUR, 1, 2) F_MMA(CUR, 1, 3)                                          \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    F_BUILD(NXT, 0) F_MMA(CUR, 2, 0) __builtin_amdgcn_sched_barrier(0);        \
+    F_BUILD(NXT, 1) F_MMA(CUR, 2, 1) __builtin_amdgcn_sched_barrier(0);        \
+    F_BUILD(NXT, 2) F_MMA(CUR, 2, 2) __builtin_amdgcn_sched_barrier(0);        \
+    F_BUILD(NXT, 3) F_MMA(CUR, 2, 3) __builtin_amdgcn_sched_barrier(0);        \
+    F_BUILD(NXT, 4) F_MMA(CUR, 3, 0) __builtin_amdgcn_sched_barrier(0);        \
+    F_BUILD(NXT, 5) F_MMA(CUR, 3, 1) __builtin_amdgcn_sched_barrier(0);        \
+    F_BUILD(NXT, 6) F_MMA(CUR, 3, 2) __builtin_amdgcn_sched_barrier(0);        \
+    F_BUILD(NXT, 7) F_MMA(CUR, 3, 3) __builtin_amdgcn_sched_barrier(0);        \
+  }
+
+  // slice 0 of stage 0
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    F_READ(k, 0, 0)
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    F_BUILD(0, k)
+  }
+  uint32_t buf = 0;  // buffer of the k-step being multiplied
+  // k-step s requests stage s + 4 into the buffer stage s - 1 left: every
+  // wavefront finished reading it before the hand-over of k-step s - 1.
+  Addr pa = addr_of(kStages - 1, kStages - 1);
+#define F_KSTEP                                                                \
+  {                                                                            \
+    const uint32_t nbuf = buf == kStages - 1 ? 0 : buf + 1;                    \
+    F_SLICE(0, 1, buf, 1, false, pa, 0)                                        \
+    F_SLICE(1, 0, nbuf, 0, true, pa, 1)                                        \
+    pa = addr_next(pa, step + kStages, buf);                                   \
+    buf = nbuf;                                                                \
+    ++step;                                                                    \
+  }
+  uint32_t step = 0;
+  while (step + 1 < num_steps) {
+    F_KSTEP
+    F_KSTEP
+  }
+  if (step < num_steps) F_KSTEP
+#undef F_KSTEP
+#undef F_SLICE
+#undef F_MMA
+#undef F_BUILD
+#undef F_PIN4
+#undef F_PINF
+#undef F_READ
+#undef F_ISSUE4
+
+  // The clamped repeats of the last stage must have landed before the stages
+  // become the epilogue's scratch.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  __syncthreads();
+
+  // --- epilogue: the bound, per pair.  C layout of the 32 x 32 MFMA: column =
+  // lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+  float2 *const st_rows = reinterpret_cast<float2 *>(lds);  // (u, t |H| + margin) per row
+  float2 *const st_cols = st_rows + kT;
+  {
+    const float t = 2.f - 4.f * a.kin_threshold;
+    float2 r = a.sample_stats[(uint64_t)tr * kT + threadIdx.x];
+    float2 c = a.sample_stats[(uint64_t)a.geo.col_base + (uint64_t)tc * kT + threadIdx.x];
+    r.y = fmaf(t, r.y, 8.f);
+    c.y = fmaf(t, c.y, 8.f);
+    st_rows[threadIdx.x] = r;
+    st_cols[threadIdx.x] = c;
+  }
+  __syncthreads();
+  float2 sc[4];
+#pragma unroll
+  for (int bj = 0; bj < 4; ++bj) sc[bj] = st_cols[wx * 128 + bj * 32 + lr];
+
+  uint32_t total = 0, base = 0, run = 0;  // wave-uniform
+#pragma nounroll
+  for (int pass = 0; pass < 2; ++pass) {  // 0: count the candidates, 1: append them
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t row = wy * 128 + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        const float2 sr = st_rows[row];
+        const uint32_t li = tr * kT + row;
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj) {
+          const uint32_t lj = tc * kT + wx * 128 + bj * 32 + lr;
+          // cuking.cu:199 plus the tile padding
+          const bool valid = li < a.geo.num_rows && lj < a.geo.num_cols &&
+                             a.i_begin + li < a.j_begin + lj;
+          // u_i + u_j - 2 q  <  t min(|H_i|, |H_j|) + margin   (acc = 4 q)
+          const float x_lb = fmaf(-0.5f, acc[bi][bj][r], sr.x + sc[bj].x);
+          const bool cand = valid && x_lb < fminf(sr.y, sc[bj].y);
+          const unsigned long long b = __ballot(cand);
+          if (b != 0) {  // wave-uniform
+            if (pass == 0) {
+              total += (uint32_t)__popcll(b);
+            } else {
+              const uint32_t before = __builtin_amdgcn_mbcnt_hi(
+                  (uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+              if (cand) a.cand_list[base + run + before] = make_uint2(li, lj);
+              run += (uint32_t)__popcll(b);
+            }
+          }
+        }
+      }
+    }
+    if (pass == 0) {
+      if (total == 0) break;  // wave-uniform: the usual case
+      bool dense = total > a.quadrant_cap;
+      if (!dense) {
+        uint32_t got = 0;
+        if (lane == 0)
+          got = __hip_atomic_fetch_add(a.filter_ctrl, total, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane(got);
+        if (base >= a.cand_cap || total > a.cand_cap - base) {
+          // list full: the slots taken (if any) must not be read as pairs
+          for (uint32_t k = base + lane; k < a.cand_cap; k += 64)
+            a.cand_list[k] = make_uint2(kNoPair, kNoPair);
+          dense = true;
+        }
+      }
+      if (dense) {
+        if (lane == 0) {
+          const uint32_t slot = __hip_atomic_fetch_add(a.filter_ctrl + 1, 1u, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+          if (slot < a.dense_cap) a.dense_list[slot] = make_uint2(2 * tr + wy, 2 * tc + wx);
+        }
+        break;
+      }
+    }
+  }
+}
+
+// One wavefront per candidate pair: the reference's six sums (cuking.cu:219-239)
+// straight from the bitset, kinship, threshold, record (cuking.cu:284-313).
+__global__ __launch_bounds__(256) void king_refine_kernel(const TiledArgs a) {
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t count = *a.filter_ctrl;
+  if (count > a.cand_cap) count = a.cand_cap;
+  const uint32_t n = a.words_per_sample / 2;
+  const uint32_t stride = gridDim.x * 4;
+  for (uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6); p < count; p += stride) {
+    const uint2 e = a.cand_list[p];
+    if (e.x == kNoPair) continue;  // (uniform: a slot of a quadrant that went dense)
+    const uint32_t off_j = a.geo.diag ? e.y : a.geo.num_rows + e.y;
+    const uint64_t *het_i_w = a.bits + (uint64_t)e.x * a.words_per_sample;
+    const uint64_t *alt_i_w = het_i_w + n;
+    const uint64_t *het_j_w = a.bits + (uint64_t)off_j * a.words_per_sample;
+    const uint64_t *alt_j_w = het_j_w + n;
+    uint32_t s_het_i = 0, s_het_j = 0, s_both = 0, s_opp = 0, s_conc = 0, s_shared = 0;
+    constexpr uint32_t kAhead = 4;  // words per lane and plane requested before any is counted
+    for (uint32_t w0 = 0; w0 < n; w0 += 64 * kAhead) {
+      uint64_t hi[kAhead], ai[kAhead], hj[kAhead], aj[kAhead];
+#pragma unroll
+      for (uint32_t k = 0; k < kAhead; ++k) {
+        const uint32_t w = w0 + 64 * k + lane;
+        const bool in = w < n;  // beyond the plane: missing
+        hi[k] = in ? het_i_w[w] : ~0ull;
+        ai[k] = in ? alt_i_w[w] : ~0ull;
+        hj[k] = in ? het_j_w[w] : ~0ull;
+        aj[k] = in ? alt_j_w[w] : ~0ull;
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < kAhead; ++k) {
+        const uint64_t ri = ~(hi[k] | ai[k]), rj = ~(hj[k] | aj[k]);
+        const uint64_t defined = ~((hi[k] & ai[k]) | (hj[k] & aj[k]));
+        s_het_i += __popcll(hi[k] & defined);
+        s_het_j += __popcll(hj[k] & defined);
+        s_both += __popcll(hi[k] & hj[k] & defined);
+        s_opp += __popcll(((ri & aj[k]) | (ai[k] & rj)) & defined);
+        s_conc += __popcll(((ri & rj) | (ai[k] & aj[k])) & defined);
+        s_shared += __popcll(defined);
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      s_het_i += __shfl_xor(s_het_i, off);
+      s_het_j += __shfl_xor(s_het_j, off);
+      s_both += __shfl_xor(s_both, off);
+      s_opp += __shfl_xor(s_opp, off);
+      s_conc += __shfl_xor(s_conc, off);
+      s_shared += __shfl_xor(s_shared, off);
+    }
+    if (lane == 0) {
+      const float kin = king_kinship(s_het_i, s_het_j, s_both, s_opp);
+      if (kin > a.kin_threshold) {
+        const uint32_t ibs0 = s_opp, ibs2 = s_conc + s_both;
+        emit_result(a.i_begin + e.x, a.j_begin + e.y, kin, ibs0, s_shared - ibs0 - ibs2, ibs2,
+                    a.max_results, a.results, a.result_index, a.result_overflow);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t launch_sample_stats(const uint64_t *d_bit_sets, uint32_t words_per_sample,
+                               const PlaneGeometry &geo, uint4 *d_planes, uint32_t s_begin,
+                               uint32_t s_end, hipStream_t stream) {
+  if (s_end > geo.s_stride) s_end = geo.s_stride;
+  if (s_begin >= s_end) return hipSuccess;
+  float2 *stats = const_cast<float2 *>(plane_stats(d_planes, geo));
+  sample_stats_kernel<<<dim3((s_end - s_begin + 3) / 4), dim3(256), 0, stream>>>(
+      d_bit_sets, words_per_sample, geo, stats, s_begin, s_end);
+  return hipGetLastError();
+}
+
+hipError_t launch_filter(const TiledArgs &args, uint64_t num_tiles, hipStream_t stream) {
+  if ((uint64_t)args.geo.k_words * 32 > kMfmaN4MaxSites || args.filter_ctrl == nullptr ||
+      args.cand_list == nullptr || args.dense_list == nullptr || args.sample_stats == nullptr)
+    return hipErrorInvalidValue;
+  static DeviceOnce attr_set;  // per device, see king_device.h
+  if (!attr_set.done()) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(king_filter_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)kFilterLdsBytes);
+    if (e != hipSuccess) return e;
+    attr_set.mark();
+  }
+  uint64_t cap = max_blocks_per_launch(256);
+  if (cap > kFilterChunkTiles) cap = kFilterChunkTiles;
+  // (a chunk's quadrants must fit the dense list)
+  if (cap > args.dense_cap / 4) cap = args.dense_cap / 4;
+  if (cap == 0) return hipErrorInvalidValue;
+  const uint32_t wgs = args.split_wgs != 0 ? args.split_wgs : 256;  // one per CU
+  uint64_t done = 0;
+  while (done < num_tiles) {
+    const uint64_t n = num_tiles - done < cap ? num_tiles - done : cap;
+    hipError_t e = hipMemsetAsync(args.filter_ctrl, 0, 16, stream);
+    if (e != hipSuccess) return e;
+    TiledArgs a = args;
+    a.tile_begin = args.tile_begin + done;
+    a.quad = 0;
+    a.tile_list = nullptr;
+    uint64_t grid = n;
+    if (args.xcd_chunk == 2 && n >= 64) {  // patches of 32, dealt round-robin to the XCDs
+      a.launch_tiles = (uint32_t)n;
+      a.xcd_chunk = 1;
+      grid = 8ull * 32 * ((((n + 31) / 32) + 7) / 8);
+    } else {
+      a.xcd_chunk = 0;
+    }
+    king_filter_kernel<<<dim3((uint32_t)grid), dim3(256), kFilterLdsBytes, stream>>>(a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    king_refine_kernel<<<dim3(wgs * 4), dim3(256), 0, stream>>>(a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    TiledArgs d = a;
+    d.tile_list = a.dense_list;
+    d.tile_list_count = a.filter_ctrl + 1;
+    d.tile_list_cap = a.dense_cap;
+    e = launch_mfma_list(d, wgs, stream);
+    if (e != hipSuccess) return e;
+    done += n;
+  }
+  return hipSuccess;
+}
+
+}  // namespace cuking

@@ -706,6 +706,10 @@ const TiledVariant kVariants[kNumTiledVariants] = {
     // Matrix cores, four plane products on one fp4 code per site: 32 KiB LDS
     // stages (king_mfma.hip).
     {"t128_mfma_fp4_n4", 128, 8, 256, kMfmaN4LdsBytes, kLayoutNibble},
+    // Matrix cores, ONE plane product as a bound on kinship + exact recount of
+    // what it lets through: 256 x 256 pairs per workgroup, 128 sites per k-step
+    // (king_filter.hip).
+    {"t256_mfma_fp4_filter", kFilterTile, 8, 256, kFilterLdsBytes, kLayoutNibbleStats},
 #ifdef CUKING_TUNING
     {"phased_both_barriers", 64, 16, 512, 2 * 2 * 16 * 64 * 16, kLayoutWord},
     {"phased_bar_before_popcount_only", 64, 16, 512, 2 * 2 * 16 * 64 * 16, kLayoutWord},
@@ -746,13 +750,29 @@ hipError_t launch_tiled(int variant, bool full, const TiledArgs &args,
     case 4: return CUKING_SHAPE(16, 16, 4, 4, 16, 2, 4);
     case kMfmaVariant: return launch_mfma(full, false, args, num_tiles, lds, stream);
     case kMfmaN4Variant: return launch_mfma(full, true, args, num_tiles, lds, stream);
+    case kMfmaFilterVariant: {
+      // The bound only helps the lean form with a threshold inside (0, 1/2);
+      // otherwise the four-product kernel runs on the quadrants of the same
+      // 256-sample tiles.
+      const bool filter = !full && args.dense_counts == nullptr && args.quad == 0 &&
+                          args.kin_threshold > 0.f && args.kin_threshold < 0.5f &&
+                          args.filter_ctrl != nullptr;
+      if (filter) return launch_filter(args, num_tiles, stream);
+      TiledArgs a = args;
+      if (a.quad == 0) {
+        a.quad = 1;
+        a.tile_begin = args.tile_begin * 4;
+        num_tiles *= 4;
+      }
+      return launch_mfma(full, true, a, num_tiles, kMfmaN4LdsBytes, stream);
+    }
 #ifdef CUKING_TUNING
-    case 7: return CUKING_PHASED(16, 2);
-    case 8: return CUKING_PHASED(16, 3);
-    case 9: return CUKING_PHASED(8, 1);
-    case 10: return launch_variant<16, 16, 4, 4, 8, 2, 4, false, 1>(args, num_tiles, lds, stream);
-    case 11: return launch_variant<16, 16, 4, 4, 8, 2, 4, false, 2>(args, num_tiles, lds, stream);
-    case 12: return launch_variant<16, 16, 4, 4, 8, 1, 5, false, 4>(args, num_tiles, lds, stream);
+    case 8: return CUKING_PHASED(16, 2);
+    case 9: return CUKING_PHASED(16, 3);
+    case 10: return CUKING_PHASED(8, 1);
+    case 11: return launch_variant<16, 16, 4, 4, 8, 2, 4, false, 1>(args, num_tiles, lds, stream);
+    case 12: return launch_variant<16, 16, 4, 4, 8, 2, 4, false, 2>(args, num_tiles, lds, stream);
+    case 13: return launch_variant<16, 16, 4, 4, 8, 1, 5, false, 4>(args, num_tiles, lds, stream);
 #endif
     default: return hipErrorInvalidValue;
   }
@@ -768,20 +788,25 @@ hipError_t launch_prepare_planes(uint32_t layout, const uint64_t *d_bit_sets,
   const uint32_t all = (geo.s_stride + kPrepSamples - 1) / kPrepSamples;
   if (s_tile_end > all) s_tile_end = all;
   if (s_tile_begin >= s_tile_end) return hipSuccess;
-  const uint32_t block_words = layout == kLayoutNibble ? kNibWords : kPrepWords;
+  const bool nibble = layout == kLayoutNibble || layout == kLayoutNibbleStats;
+  const uint32_t block_words = nibble ? kNibWords : kPrepWords;
   const dim3 grid(s_tile_end - s_tile_begin,
                   (geo.k_words + 2 * block_words - 1) / (2 * block_words));
   if (grid.y == 0) return hipSuccess;
   if (layout == kLayoutQuad)
     prepare_quads_kernel<<<grid, dim3(256), 0, stream>>>(
         d_bit_sets, words_per_sample, geo, d_planes, s_tile_begin);
-  else if (layout == kLayoutNibble)
+  else if (nibble)
     prepare_nibbles_kernel<<<grid, dim3(256), 0, stream>>>(
         d_bit_sets, words_per_sample, geo, d_planes, s_tile_begin);
   else
     prepare_planes_kernel<<<grid, dim3(256), 0, stream>>>(
         d_bit_sets, words_per_sample, geo, d_planes, s_tile_begin);
-  return hipGetLastError();
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && layout == kLayoutNibbleStats)
+    e = launch_sample_stats(d_bit_sets, words_per_sample, geo, d_planes,
+                            s_tile_begin * kPrepSamples, s_tile_end * kPrepSamples, stream);
+  return e;
 }
 
 hipError_t launch_stream(const cuking_submatrix &sm, uint32_t words_per_sample,

@@ -319,6 +319,14 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
                            : x * a.xcd_chunk + j;
     if (bid >= a.launch_tiles) return;  // padding (uniform)
   }
+  // Tile-list mode (king_common.h): entries bid, bid + grid, ... of the list.
+  const bool listed = !SPLIT && a.tile_list != nullptr;
+  uint32_t list_count = 0;
+  if (listed) {
+    list_count = *a.tile_list_count;
+    if (list_count > a.tile_list_cap) list_count = a.tile_list_cap;
+    if (bid >= list_count) return;  // uniform
+  }
   bid = __builtin_amdgcn_readfirstlane(bid);
   piece = __builtin_amdgcn_readfirstlane(piece);
 
@@ -365,6 +373,13 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   uint64_t next_tile = 0;
 #endif
   while (true) {
+  if (listed && unit_lo >= unit_hi) {
+    bid += gridDim.x;
+    if (bid >= list_count) break;
+    __syncthreads();  // every wavefront is through with the stages of the last tile
+    unit_lo = (uint64_t)bid * tile_steps;
+    unit_hi = unit_lo + tile_steps;
+  }
   if (unit_lo >= unit_hi) {
     if (!strided || next_tile >= a.split_tiles) break;
     unit_lo = next_tile * tile_steps;
@@ -1706,6 +1721,20 @@ hipError_t launch_form(bool full, bool split, bool nibble, const TiledArgs &a, u
               : launch_shape<false, false>(a, blocks, lds_bytes, stream);
 }
 }  // namespace
+
+hipError_t launch_mfma_list(const TiledArgs &args, uint32_t grid, hipStream_t stream) {
+  if ((uint64_t)args.geo.k_words * 32 > kMfmaN4MaxSites || args.tile_list == nullptr)
+    return hipErrorInvalidValue;
+  TiledArgs a = args;
+  a.quad = 0;
+  a.tile_begin = 0;
+  a.rect_rows = 0;
+  a.split_tiles = a.split_whole = 0;
+  a.split_scratch = a.split_counters = nullptr;
+  a.xcd_chunk = 0;  // (launch_shape: plain order, no dynamic tail)
+  a.dyn_tiles = a.dyn_wgs = 0;
+  return launch_shape<false, false, 0, true>(a, grid, kMfmaN4LdsBytes, stream);
+}
 
 hipError_t launch_mfma(bool full, bool nibble, const TiledArgs &args, uint64_t num_tiles,
                        uint32_t lds_bytes, hipStream_t stream) {
