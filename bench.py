@@ -59,9 +59,13 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_FP4_PEAK_TFLOPS = 10000.0
 # king_mfma.hip: plane products per pair and site, one multiply-add = 2 FLOP, by
 # kernel variant (5: five-product form on the quad layout; 6: four-product form
-# on the nibble layout).
-MFMA_MACS_PER_PAIR_SITE = {5: {"lean": 5, "full": 6}, 6: {"lean": 4, "full": 5}}
-MFMA_VARIANTS = (5, 6)
+# on the nibble layout; 7: the filter variant, king_filter.hip -- ONE product for
+# every pair when the lean form runs with a threshold inside (0, 1/2), the exact
+# sums only for the candidates that bound lets through; otherwise variant 6's
+# kernel on the quadrants of its 256-sample tiles).
+MFMA_MACS_PER_PAIR_SITE = {5: {"lean": 5, "full": 6}, 6: {"lean": 4, "full": 5},
+                           7: {"lean": 1, "full": 5}}
+MFMA_VARIANTS = (5, 6, 7)
 MFMA_N4_MAX_SITES = 1 << 22
 NOMINAL_CLOCK_HZ = 2.4e9        # MI355X_MICROARCH.md: max clock
 NUM_SIMDS = 256 * 4
@@ -239,12 +243,15 @@ def roofline_block(args, ctx, *, launch_pairs, sites, wps, thr, king_ms, prepare
     import cuking_amd
     bpp = cuking_amd.bytes_per_pair(wps)
     variant = ctx.get_option("variant")
-    if variant == 6 and 32 * wps > MFMA_N4_MAX_SITES:
+    if variant in (6, 7) and 32 * wps > MFMA_N4_MAX_SITES:
         variant = 5          # (the library hands wider bitsets to the five-product form)
     mfma = args.kernel == "tiled" and variant in MFMA_VARIANTS and 32 * wps <= (1 << 24)
-    kernel_name = ("king_stream_kernel" if args.kernel == "stream" else
-                   "king_mfma_kernel" if mfma else "king_tiled_kernel")
     form = counts_form(args, thr, wps, variant)
+    if variant == 7 and not (form == "lean" and 0.0 < thr < 0.5):
+        variant = 6          # (no bound to apply: the four-product kernel, quadrant mode)
+    kernel_name = ("king_stream_kernel" if args.kernel == "stream" else
+                   "king_filter_kernel" if mfma and variant == 7 else
+                   "king_mfma_kernel" if mfma else "king_tiled_kernel")
     achieved = launch_pairs * bpp / (king_ms * 1e-3) / 1e9 if king_ms > 0 else 0.0
     hbm_view = {
         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -295,8 +302,12 @@ def roofline_block(args, ctx, *, launch_pairs, sites, wps, thr, king_ms, prepare
                     "(padding of tiles and of the last k-step not counted); `frac` is the "
                     "share of the dense FP4 peak those products take, "
                     "`frac_five_product_equivalent` prices the same time at the five-product "
-                    "form of rounds 1-2; peak at the nominal 2.4 GHz, the chip holds less "
-                    "under this load (sustained_clock_mhz)",
+                    "form of rounds 1-2 (above 1.0 for the filter variant: it issues one "
+                    "product where that form issued five); peak at the nominal 2.4 GHz, the "
+                    "chip holds less under this load (sustained_clock_mhz)" +
+                    ("; filter variant: kernel_ms spans the filter kernel AND the refine / "
+                     "dense-quadrant kernels behind it (one event pair per call), the "
+                     "algorithmic FLOP are the filter kernel's" if variant == 7 else ""),
             "hbm": hbm_view,
         }
     roofline = {"bound": "hbm", **hbm_view, **common}

@@ -158,7 +158,7 @@ int default_variant() {
     const int k = atoi(v);
     if (k >= 0 && k < kNumTiledVariants) return k;
   }
-  return kMfmaN4Variant;
+  return kMfmaFilterVariant;
 }
 
 // The variant that runs for a bitset of this width: the matrix-core variant

@@ -243,7 +243,7 @@ constexpr uint32_t kFilterTile = 256;
 constexpr uint32_t kFilterLdsBytes = 5 * 2 * 2 * 2 * 256 * 16;  // 5 x 32 KiB
 static_assert(kFilterLdsBytes <= 160 * 1024, "LDS of one CU");
 // Per launch chunk: at most this many 256-tiles (bounds the dense-quadrant list).
-constexpr uint32_t kFilterChunkTiles = 1u << 16;
+constexpr uint32_t kFilterChunkTiles = 1u << 17;
 constexpr uint32_t kFilterCandCap = 1u << 20;      // candidate pairs per chunk
 constexpr uint32_t kFilterQuadrantCap = 1024;      // candidates per 128 x 128 quadrant
 constexpr size_t kFilterCtrlBytes = 256;

@@ -88,11 +88,15 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
         world = int(rng.integers(1, 9))
         chunks = int(rng.integers(1, 9))
         streams = [int(rng.integers(1, 4)) for _ in range(world)]
+        # filter variant: who computes a pair exactly (candidate list / dense quadrants)
+        qcap = int(rng.choice([1024, 1024, 0, 2]))
+        ccap = int(rng.choice([1 << 20, 1 << 20, 0, 5]))
         if case < first_case:
             continue
         tag = dict(fuzzer="run_general", seed=seed, case=case, n=n, m=m, split_factor=k,
                    shard=shard, thr=thr, kernel=kernel, variant=variant, counts_mode=mode,
-                   xcd_swizzle=swizzle, band_rows=band, split_wgs=wgs, reuse_prepared=reuse)
+                   xcd_swizzle=swizzle, band_rows=band, split_wgs=wgs, reuse_prepared=reuse,
+                   filter_quadrant_cap=qcap, filter_cand_cap=ccap)
         osm = pyoracle.submatrix(n, k, shard)
         bits = pyoracle.bitset_from_genotypes(geno, osm)
         exp, _, _ = pyoracle.compute(osm, bits, thr, threads=8)
@@ -103,6 +107,8 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
         ctx.set_option("xcd_swizzle", swizzle)
         ctx.set_option("band_rows", band)
         ctx.set_option("split_wgs", wgs)
+        ctx.set_option("filter_quadrant_cap", qcap)
+        ctx.set_option("filter_cand_cap", ccap)
         # (a new bitset may land on a recycled pointer: tell the library)
         ctx.set_option("reuse_prepared", reuse)
         ctx.invalidate()
@@ -132,6 +138,8 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
         if log and case % 25 == 0:
             log(f"run_general seed {seed} case {case} ok ({time.time() - t0:.0f}s)")
     ctx.set_option("reuse_prepared", 0)
+    ctx.set_option("filter_quadrant_cap", 1024)
+    ctx.set_option("filter_cand_cap", 1 << 20)
     return ran
 
 

@@ -202,7 +202,8 @@ def test_weighted_tile_ranges_and_calibration_plan(tmp_path):
     share = got["num_tiles"] // 8
     assert got["weighted"] is False
     assert got["calibration_tiles"] % 256 == 0
-    assert 0.015 * share <= got["calibration_tiles"] <= 0.021 * share
+    # (... at least 8 rounds: the floor at 256-sample tiles for this cohort)
+    assert min(0.015 * share, 2048) <= got["calibration_tiles"] <= max(0.021 * share, 2048)
     assert schedule("--calibrate=false")["calibration_tiles"] == 0
     assert schedule("--calibration_tiles=512")["calibration_tiles"] == 512
     # small jobs do not calibrate

@@ -167,7 +167,8 @@ def _worker(rank, world, port, n, m, thr, max_results, out_path):
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_pass_equals_single_pass(tmp_path, world):
     out = tmp_path / "result.txt"
-    mp.spawn(_worker, args=(world, _free_port(), 200, 300, -0.1, 100000, str(out)),
+    # (600 samples: three rows of the default variant's 256-sample tiles)
+    mp.spawn(_worker, args=(world, _free_port(), 600, 300, 0.02, 100000, str(out)),
              nprocs=world, join=True)
     status, same, n_exp, tiles = out.read_text().split()
     assert status == "ok" and same == "1"

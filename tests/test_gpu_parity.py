@@ -18,8 +18,8 @@ from conftest import GOLDEN, random_genotypes
 
 pytestmark = pytest.mark.gpu
 
-NUM_VARIANTS = 7   # 0-4 VALU shapes, 5 / 6 matrix cores: five / four products (cuking_variant_name)
-MFMA_VARIANTS = [5, 6]
+NUM_VARIANTS = 8   # 0-4 VALU shapes, 5 / 6 / 7 matrix cores: five / four products, filter (cuking_variant_name)
+MFMA_VARIANTS = [5, 6, 7]
 KERNELS = [("stream", 0)] + [("tiled", v) for v in range(NUM_VARIANTS)]
 
 
@@ -212,7 +212,7 @@ def test_tile_ranges_union(ctx, oracle, variant):
         ctx.run(sm, bits.shape[1], d_bits, -0.05, tile_range=(0, tiles + 1))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 4, 5, 6, 7])
 @pytest.mark.parametrize("world,chunks", [(1, 1), (1, 4), (2, 3), (3, 8), (8, 5)])
 def test_staged_rectangles_union(ctx, oracle, variant, world, chunks):
     """The overlapped multi-GPU schedule (chunked arrival, row bands, rectangle
@@ -364,7 +364,9 @@ def test_matrix_core_remainder_split(ctx, oracle, thr, counts_mode, mv):
 
 @pytest.mark.parametrize("mv,sites", [(5, (1 << 24) - 256), (5, (1 << 24) + 512),
                                       (6, (1 << 22) - 256), (6, (1 << 22) + 512),
-                                      (6, (1 << 24) + 512)])
+                                      (6, (1 << 24) + 512),
+                                      (7, (1 << 22) - 256), (7, (1 << 22) + 512),
+                                      (7, (1 << 24) + 512)])
 def test_matrix_core_float_limit(ctx, oracle, mv, sites):
     """The matrix-core variants count in float32: exact while every sum stays
     below 2^24.  Just under the limit with sums as large as they get (every
@@ -372,7 +374,8 @@ def test_matrix_core_float_limit(ctx, oracle, mv, sites):
     library switches to the VALU variant with the same tile geometry.  The
     four-product variant decides kinship on an integer that equals the reference's
     float expression below 2^22 sites: from there on it hands over to the
-    five-product one."""
+    five-product one; so does the filter variant (its accumulators hold 4 q), on the
+    quadrants of its 256-sample tiles."""
     select(ctx, "tiled", mv)
     n = 20
     wps = cuking_amd.words_per_sample(sites)
@@ -389,13 +392,20 @@ def test_matrix_core_float_limit(ctx, oracle, mv, sites):
         bits[:, wps // 2 - 1] |= tail
     osm = oracle.submatrix(n)
     exp, _, _ = oracle.compute(osm, bits, -1e30, threads=8)
-    got = ctx.run(cuking_amd.Submatrix(n), wps, ctx.upload_bitset(bits), -1e30)
+    d_bits = ctx.upload_bitset(bits)
+    got = ctx.run(cuking_amd.Submatrix(n), wps, d_bits, -1e30)
     assert got.tobytes() == exp.tobytes()
     assert int(exp["ibs2"].max()) + int(exp["ibs1"].max()) > sites // 2   # sums as large as they get
+    # ... and with a threshold the lean forms (and the filter variant's bound) apply to
+    ctx.set_option("counts_mode", 0)
+    exp, _, _ = oracle.compute(osm, bits, 0.2, threads=8)
+    assert len(exp) >= 1
+    assert ctx.run(cuking_amd.Submatrix(n), wps, d_bits, 0.2).tobytes() == exp.tobytes()
     select(ctx, "tiled", 0)
 
 
-@pytest.mark.parametrize("kernel,variant", [("tiled", 5), ("tiled", 6), ("tiled", 0), ("stream", 0)])
+@pytest.mark.parametrize("kernel,variant", [("tiled", 5), ("tiled", 6), ("tiled", 7), ("tiled", 0),
+                                            ("stream", 0)])
 def test_site_position_patterns(ctx, oracle, kernel, variant):
     """Genotype patterns that single out one site position: the matrix-core
     kernel expands sites by their position inside a 4-site nibble (position 3 is
@@ -431,7 +441,7 @@ def test_options_round_trip(ctx):
     kernel variant is the matrix-core one."""
     fresh = cuking_amd.KingContext(0)
     try:
-        assert fresh.get_option("variant") == 6 and fresh.variant_name() == "t128_mfma_fp4_n4"
+        assert fresh.get_option("variant") == 7 and fresh.variant_name() == "t256_mfma_fp4_filter"
         assert fresh.get_option("split_wgs") > 0 and fresh.get_option("counts_mode") == -1
         assert fresh.get_option("xcd_swizzle") == 2 and fresh.get_option("band_rows") == 0
         for key, value in (("variant", 2), ("band_rows", 9), ("counts_mode", 1), ("split_wgs", 0),
@@ -769,7 +779,7 @@ def test_rect_needs_prepared_samples(ctx, oracle):
         assert ovf == 0 and got.tobytes() == whole.tobytes() == exp.tobytes()
 
 
-@pytest.mark.parametrize("variant", [0, 5, 6])
+@pytest.mark.parametrize("variant", [0, 5, 6, 7])
 def test_calls_on_two_streams_of_one_context(ctx, oracle, variant):
     """Two blocks back to back on two non-blocking streams of ONE context: the
     second call's layout conversion overwrites the workspace the first call's
@@ -815,7 +825,7 @@ def test_tile_order_options_do_not_change_results(ctx, oracle, split_wgs, mv):
     select(ctx, "tiled", mv)
     ctx.set_option("split_wgs", split_wgs)
     rng = np.random.default_rng(99)
-    n, m = 2700, 700                       # 22 tile rows: 253 tiles
+    n, m = 2700, 700                       # 22 rows of 128-sample tiles: 253 tiles; 11 of 256: 66
     geno = random_genotypes(rng, n, m, missing=0.03)
     geno[n - 1], geno[1500] = geno[7], geno[130]
     bits = oracle.bitset_from_genotypes(geno)
@@ -830,9 +840,10 @@ def test_tile_order_options_do_not_change_results(ctx, oracle, split_wgs, mv):
                 got = ctx.run(sm, bits.shape[1], d_bits, 0.06, max_results=1 << 20)
                 assert got.tobytes() == exp.tobytes(), (swz, rows)
                 tiles = ctx.num_tiles(sm)
+                cut = 2 * tiles // 5
                 parts = [ctx.run(sm, bits.shape[1], d_bits, 0.06, max_results=1 << 20,
                                  tile_range=r, sort=False)
-                         for r in ((0, 100), (100, 101), (101, tiles))]
+                         for r in ((0, cut), (cut, cut + 1), (cut + 1, tiles))]
                 merged = cuking_amd.sort_results(np.concatenate(parts))
                 assert merged.tobytes() == exp.tobytes(), (swz, rows, "ranges")
         # an off-diagonal block as well (no triangle in the enumeration)
@@ -1083,7 +1094,7 @@ def test_reserved_workspace_means_no_allocation_and_no_host_wait(oracle):
         c.close()
 
 
-@pytest.mark.parametrize("variant", [5, 6, 0])
+@pytest.mark.parametrize("variant", [5, 6, 7, 0])
 def test_reuse_prepared_layout_and_invalidate(oracle, variant):
     """Option "reuse_prepared": a repeated call on the same (block, width, shape,
     bitset pointer) launches the pair kernel only; a host that rewrites the bitset
@@ -1142,3 +1153,73 @@ def test_reuse_prepared_layout_and_invalidate(oracle, variant):
         assert c.run(half, wps, other, thr).tobytes() == exp_half.tobytes()
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("missing", [0.0, 0.02, 0.35])
+def test_filter_variant_every_path_gives_the_oracle_records(ctx, oracle, missing):
+    """The filter variant (king_filter.hip) decides with a bound WHO computes a pair
+    exactly: candidate list + one wavefront per pair, or the four-product kernel
+    over a dense quadrant.  Whatever the missingness (0.35: the bound lets most
+    pairs through, whole quadrants go dense), however short the list and however
+    small the launch chunks, the records are the oracle's."""
+    select(ctx, "tiled", 7)
+    rng = np.random.default_rng(int(missing * 100) + 3)
+    n, m = 1100, 2500                         # 5 x 5 tiles of 256, the last one ragged
+    geno = random_genotypes(rng, n, m, missing=missing)
+    # a family of 30 near-identical samples inside one quadrant, relatives across tiles
+    for k in range(30):
+        geno[300 + k] = np.where(rng.random(m) < 0.02, geno[5], geno[300])
+    geno[n - 1], geno[700], geno[1023] = geno[2], geno[130], geno[256]
+    bits = oracle.bitset_from_genotypes(geno)
+    d_bits = ctx.upload_bitset(bits)
+    sm = cuking_amd.Submatrix(n)
+    off = cuking_amd.Submatrix(n, 2, 1)
+    idx = list(range(off.i_begin, off.i_end)) + list(range(off.j_begin, off.j_end))
+    sub = np.ascontiguousarray(bits[idx])
+    d_sub = ctx.upload_bitset(sub)
+    defaults = {"filter_quadrant_cap": 1024, "filter_cand_cap": 1 << 20, "max_launch_blocks": 0}
+    try:
+        for thr in (0.03, 0.0884, 0.2):
+            exp, _, _ = oracle.compute(oracle.submatrix(n), bits, thr, threads=16)
+            e2, _, _ = oracle.compute(oracle.submatrix(n, 2, 1), sub, thr, threads=16)
+            assert len(exp) >= 30 * 29 // 2
+            for opts in ({}, {"filter_quadrant_cap": 0}, {"filter_quadrant_cap": 3},
+                         {"filter_cand_cap": 0}, {"filter_cand_cap": 7}, {"max_launch_blocks": 2},
+                         {"filter_cand_cap": 40, "max_launch_blocks": 3}):
+                for k, v in {**defaults, **opts}.items():
+                    ctx.set_option(k, v)
+                got = ctx.run(sm, bits.shape[1], d_bits, thr, max_results=1 << 20)
+                assert got.tobytes() == exp.tobytes(), (thr, opts)
+                got = ctx.run(off, bits.shape[1], d_sub, thr, max_results=1 << 20)
+                assert got.tobytes() == e2.tobytes(), (thr, opts, "off-diagonal block")
+    finally:
+        for k, v in defaults.items():
+            ctx.set_option(k, v)
+
+
+def test_filter_variant_tile_geometry_and_fallbacks(ctx, oracle):
+    """256-sample tiles whatever runs underneath: the lean form with a threshold in
+    (0, 1/2) takes the bound; the full form, thresholds outside that range and the
+    diagnostic counts take the four-product kernel on the quadrants of the same
+    tiles -- same tile count, same tile bounds, same records."""
+    select(ctx, "tiled", 7)
+    assert ctx.tile_samples() == 256
+    rng = np.random.default_rng(77)
+    n, m = 700, 900
+    geno = random_genotypes(rng, n, m, missing=0.03)
+    geno[n - 1], geno[300] = geno[0], geno[290]
+    bits = oracle.bitset_from_genotypes(geno)
+    d_bits = ctx.upload_bitset(bits)
+    sm = cuking_amd.Submatrix(n)
+    assert ctx.num_tiles(sm) == 6           # 3 tile rows, upper triangle
+    for thr, mode in ((0.05, 0), (0.05, 1), (0.0, -1), (-0.1, 0), (0.5, 0), (0.7, -1),
+                      (float("nan"), 0)):
+        ctx.set_option("counts_mode", mode)
+        exp, _, _ = oracle.compute(oracle.submatrix(n), bits, thr)
+        got = ctx.run(sm, bits.shape[1], d_bits, thr, max_results=1 << 20)
+        assert got.tobytes() == exp.tobytes(), (thr, mode)
+        parts = [ctx.run(sm, bits.shape[1], d_bits, thr, max_results=1 << 20, tile_range=r,
+                         sort=False) for r in ((0, 1), (1, 4), (4, 6))]
+        assert cuking_amd.sort_results(np.concatenate(parts)).tobytes() == exp.tobytes(), (thr, mode)
+    ctx.set_option("counts_mode", -1)
+    check_counts(ctx, oracle, sm, bits)

@@ -9,7 +9,8 @@ independent kernel (VALU popcount variant), the union of tile ranges, and
 (c) 64-bit indexing: configs[4] holds 734,000 x 6,250 u64 words, so the
 samples at the far end sit beyond element offset 2^32 of the bitset
 (cuking.cu:205-208, :514) and beyond byte offset 2^32 of the kernel layout
-(73.4 GB in the default kernel's one-code-per-site form, beside the 36.7 GB bitset).
+(92 GB in the default kernel's one-code-per-site form with its het-only copy, beside the
+36.7 GB bitset).
 
 Times on MI355X (round 1): configs[2] 0.64 s, configs[3] geometry 8.9 s,
 configs[4] last tiles 0.6 s, whole configs[4] triangle 72 s
@@ -28,7 +29,7 @@ from cuking_amd.synth import DEFAULT_SEED, cohort_to_device, plan_cohort
 
 pytestmark = pytest.mark.gpu
 
-MFMA, MFMA5, VALU_T64, VALU_T128 = 6, 5, 1, 2   # default (four products), five products, VALU
+MFMA, MFMA4, MFMA5, VALU_T64, VALU_T128 = 7, 6, 5, 1, 2   # default (filter), four / five products, VALU
 
 
 def synthesise(ctx, n, m):
@@ -108,9 +109,17 @@ def test_c2_100k_x_100k_whole_triangle(ctx, oracle):
     assert ctx.run(sm, wps, bits, thr, max_results=4 << 20).tobytes() == res.tobytes()
     ctx.set_option("variant", VALU_T64)
     assert ctx.run(sm, wps, bits, thr, max_results=4 << 20).tobytes() == res.tobytes()
-    ctx.set_option("variant", MFMA5)          # ... and the five-product matrix-core kernel
+    ctx.set_option("variant", MFMA5)          # ... and the five- and four-product matrix-core kernels
+    assert ctx.run(sm, wps, bits, thr, max_results=4 << 20).tobytes() == res.tobytes()
+    ctx.set_option("variant", MFMA4)
     assert ctx.run(sm, wps, bits, thr, max_results=4 << 20).tobytes() == res.tobytes()
     ctx.set_option("variant", MFMA)
+    # ... the filter variant with every quadrant that has a candidate handed to the
+    # four-product kernel, and with a candidate list of 100 entries
+    for key, value, back in (("filter_quadrant_cap", 0, 1024), ("filter_cand_cap", 100, 1 << 20)):
+        ctx.set_option(key, value)
+        assert ctx.run(sm, wps, bits, thr, max_results=4 << 20).tobytes() == res.tobytes(), key
+        ctx.set_option(key, back)
     ctx.set_option("counts_mode", 1)
     assert ctx.run(sm, wps, bits, thr, max_results=4 << 20).tobytes() == res.tobytes()
     ctx.set_option("counts_mode", -1)
@@ -195,37 +204,29 @@ def test_c4_734k_x_200k_far_end_beyond_2_32_elements(ctx, oracle, c4):
         seen += check_blocks(oracle, bits, res_hi, thr,
                              [((rb.value, re_.value), (cb.value, ce.value))])
     assert far >= 2 and seen > 40_000
-    # the same far tiles from the independent VALU kernel (128-sample tiles):
-    # identical records
-    # (the band height is chosen per kernel family; pinned here so that a tile
-    #  index means the same tile for both)
-    try:
-        ctx.set_option("band_rows", 17)
-        ctx.set_option("variant", VALU_T128)
-        few = ctx.run(sm, wps, bits, thr, max_results=4 << 20, tile_range=(tiles - 3000, tiles))
-        ctx.set_option("variant", MFMA)
-        again = ctx.run(sm, wps, bits, thr, max_results=4 << 20,
-                        tile_range=(tiles - 3000, tiles))
-    finally:
-        ctx.set_option("band_rows", 0)
-        ctx.set_option("variant", MFMA)
-    assert few.tobytes() == again.tobytes() and len(few) > 0
     # far-corner rectangle through the staged operator
     lo = (n // tile - 20) * tile
     assert lo > first_far
     results = torch.zeros((1 << 20, 6), dtype=torch.int32, device="cuda:0")
     idx = torch.zeros(2, dtype=torch.int32, device="cuda:0")
-    ctx.prepare_samples(sm, wps, bits, lo, n)
-    ctx.compute_king_rect(sm, wps, bits, (lo, n), (lo, n), thr, 1 << 20, results,
-                          idx[0:1], idx[1:2])
-    torch.cuda.synchronize()
-    cnt, ovf = idx.tolist()
-    assert ovf == 0
-    recs = cuking_amd.sort_results(results[:cnt].cpu().numpy().view(np.uint32).reshape(-1).view(
-        cuking_amd.KING_RESULT_DTYPE).copy())
     exp = oracle_block(oracle, bits, thr, (lo, n), (lo, n))
-    assert recs.tobytes() == exp.tobytes() and len(exp) > 100
-    assert np.all(exp["ibs0"] + exp["ibs1"] + exp["ibs2"] <= m)
+    assert len(exp) > 100 and np.all(exp["ibs0"] + exp["ibs1"] + exp["ibs2"] <= m)
+    # ... by the default kernel and by the independent VALU kernel (128-sample tiles)
+    try:
+        for variant in (MFMA, VALU_T128):
+            ctx.set_option("variant", variant)
+            idx.zero_()
+            ctx.prepare_samples(sm, wps, bits, lo, n)
+            ctx.compute_king_rect(sm, wps, bits, (lo, n), (lo, n), thr, 1 << 20, results,
+                                  idx[0:1], idx[1:2])
+            torch.cuda.synchronize()
+            cnt, ovf = idx.tolist()
+            assert ovf == 0
+            recs = cuking_amd.sort_results(results[:cnt].cpu().numpy().view(np.uint32).reshape(-1)
+                                           .view(cuking_amd.KING_RESULT_DTYPE).copy())
+            assert recs.tobytes() == exp.tobytes(), variant
+    finally:
+        ctx.set_option("variant", MFMA)
 
 
 @pytest.mark.skipif(os.environ.get("CUKING_SKIP_WHOLE_C4") == "1",
