@@ -301,6 +301,7 @@ cuking_status split_scratch_for(cuking_ctx *ctx, hipStream_t stream,
 cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const PlaneGeometry &geo,
                                  TiledArgs *a) {
   a->sample_stats = nullptr;
+  a->t2 = nullptr;
   a->filter_ctrl = nullptr;
   a->cand_list = nullptr;
   a->dense_list = nullptr;
@@ -321,6 +322,7 @@ cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const Plan
     ctx->filter_scratch.emplace_back(stream, base);
   }
   a->sample_stats = plane_stats(ctx->planes, geo);
+  a->t2 = plane_t2(ctx->planes, geo);
   a->filter_ctrl = reinterpret_cast<uint32_t *>(base);
   a->cand_list = reinterpret_cast<uint2 *>(base + kFilterCtrlBytes);
   a->cand_cap = ctx->filter_cand_cap;

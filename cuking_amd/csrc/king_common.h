@@ -50,8 +50,13 @@ namespace cuking {
 constexpr uint32_t kLayoutWord = 0;
 constexpr uint32_t kLayoutQuad = 1;
 constexpr uint32_t kLayoutNibble = 2;
-// ... plus, behind the het-only copy, one float2 per stored sample for the
-// filter kernel (king_filter.hip): (homozygous - missing site count, het count).
+// ... plus what the filter kernel (king_filter.hip) reads, behind the het-only
+// copy: the T2 layout -- T = hom-ref minus hom-alt alone, TWO bits per site (hom,
+// hom-alt), for every unit u of 64 sites and sample s one uint4, t2[u * s_stride
+// + s]: nibble t of dword d holds site 64 u + 8 d + t in bits 2-3 (code 0100 /
+// 1100 = +-2.0 after `& 0xCCCCCCCC`) and site 64 u + 32 + 8 d + t in bits 0-1 (the
+// same code after `<< 2`), half the bytes of the codes -- and one float2 per stored
+// sample: (homozygous - missing site count, het count).
 constexpr uint32_t kLayoutNibbleStats = 3;
 
 struct PlaneGeometry {
@@ -184,6 +189,7 @@ struct TiledArgs {
   // (candidate count, dense-quadrant count), the candidate pairs and the
   // quadrants handed to the exact kernel instead.
   const float2 *sample_stats;
+  const uint4 *t2;         // the T2 layout (king_common.h, kLayoutNibbleStats)
   uint32_t *filter_ctrl;
   uint2 *cand_list;
   uint32_t cand_cap;       // entries of cand_list
@@ -199,12 +205,17 @@ __host__ __device__ inline size_t plane_bytes(const PlaneGeometry &g,
   // four words and sample; nibble layout: 16 B per 32 sites and sample.
   const size_t base = (size_t)g.k_words * g.s_stride * (layout == kLayoutQuad ? 8 : 16);
   if (layout == kLayoutNibble) return base + base / 4;  // + the het-only copy
-  if (layout == kLayoutNibbleStats) return base + base / 4 + (size_t)g.s_stride * sizeof(float2);
+  if (layout == kLayoutNibbleStats)
+    return base + base / 4 + base / 2 + (size_t)g.s_stride * sizeof(float2);
   return base;
 }
-// Where the per-sample statistics of kLayoutNibbleStats start.
+// Where the T2 layout and the per-sample statistics of kLayoutNibbleStats start
+// (k_words is a multiple of 8: whole uint4 either way).
+__host__ __device__ inline const uint4 *plane_t2(const uint4 *planes, const PlaneGeometry &g) {
+  return planes + (size_t)g.k_words * g.s_stride * 5 / 4;
+}
 __host__ __device__ inline const float2 *plane_stats(const uint4 *planes, const PlaneGeometry &g) {
-  return reinterpret_cast<const float2 *>(planes + (size_t)g.k_words * g.s_stride * 5 / 4);
+  return reinterpret_cast<const float2 *>(planes + (size_t)g.k_words * g.s_stride * 7 / 4);
 }
 
 // One compiled shape of the tiled kernel.

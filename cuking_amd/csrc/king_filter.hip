@@ -117,9 +117,17 @@ __device__ __forceinline__ v8i tfrag(const uint4 w, uint32_t mask) {
   return r;
 }
 
+// Timing-only builds (wrong results, never shipped; tools/ab_flags.sh):
+// -DCUKING_FILTER_ABLATE=1 no LDS-DMA requests, =2 no stage barrier either,
+// =3 the shipped loop without the epilogue.
+#ifndef CUKING_FILTER_ABLATE
+#define CUKING_FILTER_ABLATE 0
+#endif
+
 // One LDS-DMA request: lane l's 16 bytes of SRC + OFF land at DST + OFF + 16 l
 // (the immediate offset moves source and destination alike).
 #define F_ISSUE(SRC, DST, OFF)                                                 \
+  if (CUKING_FILTER_ABLATE != 1 && CUKING_FILTER_ABLATE != 2)                  \
   asm volatile("s_mov_b32 m0, %0\n\t"                                          \
                "s_nop 0\n\t"                                                   \
                "global_load_lds_dwordx4 %1, %2 offset:" #OFF                   \
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   // second half: block rows 2-3 with the fragment builds of the next slice.
 #define F_SLICE(CUR, NXT, RBUF, RC, SYNC, PA, DC)                              \
   {                                                                            \
-    if (SYNC) {                                                                \
+    if ((SYNC) && CUKING_FILTER_ABLATE != 2) {                                 \
       __builtin_amdgcn_s_waitcnt(vmcnt_imm(2 * 8 + 4));                        \
       __syncthreads();                                                         \
     }                                                                          \
@@ -320,6 +328,18 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   // become the epilogue's scratch.
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __syncthreads();
+
+  if (CUKING_FILTER_ABLATE != 0) {
+    float sum = 0.f;
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += acc[bi][bj][r];
+    if (sum == -1.f) a.results[0].kin = sum;  // never true, keeps the sums alive
+    return;
+  }
 
   // --- epilogue: the bound, per pair.  C layout of the 32 x 32 MFMA: column =
   // lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).

@@ -165,6 +165,8 @@ __device__ __forceinline__ uint32_t spread8(uint32_t b) {
 #endif
 constexpr int kNibWords = CUKING_NIB_WORDS;
 
+// T2: the filter kernel's two-bit layout as well (king_common.h, kLayoutNibbleStats).
+template <bool T2>
 __global__ __launch_bounds__(256) void prepare_nibbles_kernel(
     const uint64_t *__restrict__ bits, uint32_t words_per_sample,
     PlaneGeometry geo, uint4 *__restrict__ planes, uint32_t s_tile_begin) {
@@ -249,6 +251,30 @@ __global__ __launch_bounds__(256) void prepare_nibbles_kernel(
     const uint64_t lo = het_lds[s][2 * ql], hi = het_lds[s][2 * ql + 1];
     hetq[(uint64_t)q * geo.s_stride + s0 + s] =
         make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+  }
+  if constexpr (T2) {
+    // One unit = one 64-bit word of the reference planes: its low 32 sites in
+    // bits 2-3 of the nibbles, its high 32 sites in bits 0-1; per site (hom-alt,
+    // hom) = the fp4 code's (sign, 2.0) bits.
+    uint4 *t2 = const_cast<uint4 *>(plane_t2(planes, geo));
+#pragma unroll
+    for (int it = 0; it < kNibWords * kPrepSamples / 256; ++it) {
+      const uint32_t idx = it * 256 + threadIdx.x;
+      const uint32_t s = idx % kPrepSamples, ul = idx / kPrepSamples;
+      const uint32_t u = w0 + ul;
+      if (u * 2 >= geo.k_words || s0 + s >= geo.s_stride) continue;
+      const uint64_t het = het_lds[s][ul], hom = hom_lds[s][ul];
+      uint32_t out[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const uint32_t h_lo = (uint32_t)(het >> (8 * d)), m_lo = (uint32_t)(hom >> (8 * d));
+        const uint32_t h_hi = (uint32_t)(het >> (32 + 8 * d)), m_hi = (uint32_t)(hom >> (32 + 8 * d));
+        const uint32_t y_lo = spread8(~h_lo), a_lo = spread8(m_lo & ~h_lo);
+        const uint32_t y_hi = spread8(~h_hi), a_hi = spread8(m_hi & ~h_hi);
+        out[d] = (a_lo << 3) | (y_lo << 2) | (a_hi << 1) | y_hi;
+      }
+      t2[(uint64_t)u * geo.s_stride + s0 + s] = make_uint4(out[0], out[1], out[2], out[3]);
+    }
   }
 }
 
@@ -796,8 +822,11 @@ hipError_t launch_prepare_planes(uint32_t layout, const uint64_t *d_bit_sets,
   if (layout == kLayoutQuad)
     prepare_quads_kernel<<<grid, dim3(256), 0, stream>>>(
         d_bit_sets, words_per_sample, geo, d_planes, s_tile_begin);
+  else if (layout == kLayoutNibbleStats)
+    prepare_nibbles_kernel<true><<<grid, dim3(256), 0, stream>>>(
+        d_bit_sets, words_per_sample, geo, d_planes, s_tile_begin);
   else if (nibble)
-    prepare_nibbles_kernel<<<grid, dim3(256), 0, stream>>>(
+    prepare_nibbles_kernel<false><<<grid, dim3(256), 0, stream>>>(
         d_bit_sets, words_per_sample, geo, d_planes, s_tile_begin);
   else
     prepare_planes_kernel<<<grid, dim3(256), 0, stream>>>(

@@ -181,10 +181,18 @@ typedef enum cuking_kernel {
 cuking_status cuking_ctx_set_kernel(cuking_ctx *ctx, cuking_kernel kernel);
 /* Tuning knobs of the tiled kernel: "variant" (compiled kernel shape, 0 ..
  * cuking_num_variants()-1; also env CUKING_AMD_VARIANT; 0..4 are VALU
- * AND/popcount shapes, 5 and 6 the matrix-core kernels: 5 = five plane products
- * on the reference's two bit planes, 6 = four plane products on one fp4 code per
- * site, the default -- it serves bitsets below 2^22 sites and hands wider ones to
- * 5, which hands bitsets from 2^24 sites on to VALU shape 2), "split_wgs"
+ * AND/popcount shapes, 5, 6 and 7 the matrix-core kernels: 5 = five plane
+ * products on the reference's two bit planes, 6 = four plane products on one
+ * fp4 code per site, 7 = the default: ONE plane product per pair as a rigorous
+ * upper bound on kinship, and the reference's exact sums for the few pairs
+ * that bound lets through (one wavefront per candidate pair; quadrants with
+ * many candidates go to kernel 6) -- same records for any data, the bound only
+ * decides who computes a pair exactly.  It applies to the lean form with
+ * 0 < kin_threshold < 1/2; otherwise, and for the diagnostic counts, variant 7
+ * runs kernel 6 on the quadrants of its tiles.  7 has 256-sample tiles, all
+ * others 128 or 64 (cuking_tile_samples).  6 and 7 serve bitsets below 2^22
+ * sites and hand wider ones to 5, which hands bitsets from 2^24 sites on to
+ * VALU shape 2; the tile edge stays the context variant's), "split_wgs"
  * (matrix-core variant: short launches cut their remainder of tiles into this
  * many equal pieces, default one per CU, 0 = never), "band_rows"
  * (tile-rows per scheduling band, 1..64, 0 = chosen by block size, the default;
@@ -199,12 +207,16 @@ cuking_status cuking_ctx_set_kernel(cuking_ctx *ctx, cuking_kernel kernel);
  * "counts_mode" (0 = lean: four sums per pair in the main loop, the hom/hom
  * count behind IBS2 recounted only for emitted pairs; 1 = full: all five sums
  * for every pair; -1 = automatic: lean when kin_threshold > c / sqrt(sites), c = 2.05 (1.6 for the VALU variants),
- * i.e. when few pairs are expected to pass).  Results do
- * not depend on any of them. */
+ * i.e. when few pairs are expected to pass).  Test hooks of variant 7:
+ * "filter_quadrant_cap" (candidates per 128 x 128 quadrant beyond which the
+ * quadrant goes to kernel 6, default 1024) and "filter_cand_cap" (entries of the
+ * candidate list per launch, default 2^20).  Results do not depend on any of
+ * them. */
 cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
                                     int64_t value);
 /* Current value of "variant", "split_wgs", "band_rows", "xcd_swizzle",
- * "dyn_tail_tiles", "counts_mode" or "reuse_prepared"; read-only counters
+ * "dyn_tail_tiles", "counts_mode", "reuse_prepared", "filter_quadrant_cap" or
+ * "filter_cand_cap"; read-only counters
  * "workspace_allocations", "host_syncs", "conversions_skipped". */
 cuking_status cuking_ctx_get_option(const cuking_ctx *ctx, const char *key,
                                     int64_t *value);
@@ -229,10 +241,13 @@ const char *cuking_variant_name(int variant);
  * partial sum of num = 2 bh - 4 opp - hi - hj is an integer below 2^24, so the
  * value is the same for every association order and every FMA contraction a
  * compiler may apply to cuking.cu:291-294: bit-exact against the reference.
- * (The default kernel evaluates num as the integer hi + hj - 2 dd + 2 q, dd =
+ * (Variant 6 evaluates num as the integer hi + hj - 2 dd + 2 q, dd =
  * sites where both samples are defined, q = concordant - opposing homozygous
  * sites: the same integer, so the same float, below 2^22 sites; it is not used
- * beyond.)  From 2^22 sites on, this library evaluates the expression left to
+ * beyond.  The default variant's records come from the reference's own six
+ * sums and float expression, evaluated for every pair its bound admits; the
+ * bound carries a margin for both float32 roundings (csrc/king_filter.hip).)
+ * From 2^22 sites on, this library evaluates the expression left to
  * right with one float32 rounding per operation (no contraction); a reference
  * build that fuses multiply-adds may differ there in the last bit.  The
  * matrix-core variants count in float32 and serve bitsets up to 2^24 sites; wider

@@ -888,8 +888,9 @@ def test_dynamic_tail_of_a_launch(ctx, oracle, mv):
                 assert got.tobytes() == exp.tobytes(), (mode, rep)
         ctx.set_option("counts_mode", -1)
         tiles = ctx.num_tiles(sm)
+        cut = 520 * tiles // 1128              # 128-sample tiles: 520 / 1 / 607 tiles
         parts = [ctx.run(sm, bits.shape[1], d_bits, 0.07, max_results=1 << 20, tile_range=r,
-                         sort=False) for r in ((0, 520), (520, 521), (521, tiles))]   # 520 / 1 / 607 tiles
+                         sort=False) for r in ((0, cut), (cut, cut + 1), (cut + 1, tiles))]
         merged = cuking_amd.sort_results(np.concatenate(parts))
         assert merged.tobytes() == exp.tobytes()
         # the staged multi-GPU rectangles (side streams, one counter each) as well
