@@ -124,6 +124,10 @@ __device__ __forceinline__ v8i tfrag(const uint4 w, uint32_t mask) {
 #define CUKING_FILTER_ABLATE 0
 #endif
 
+__device__ __forceinline__ uint4 shl2(const uint4 w) {
+  return make_uint4(w.x << 2, w.y << 2, w.z << 2, w.w << 2);
+}
+
 // One LDS-DMA request: lane l's 16 bytes of SRC + OFF land at DST + OFF + 16 l
 // (the immediate offset moves source and destination alike).
 #define F_ISSUE(SRC, DST, OFF)                                                 \
@@ -158,24 +162,25 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   const uint32_t lr = lane & 31;                 // row / column inside a block
   uint32_t lane16 = lane * 16;
   const uint32_t s_stride = a.geo.s_stride;
-  const uint32_t num_steps = a.geo.k_words / 4;  // k-steps of 128 sites
-  const uint4 *g_rows = a.planes + (uint64_t)tr * kT;
-  const uint4 *g_cols = a.planes + a.geo.col_base + (uint64_t)tc * kT;
+  const uint32_t num_steps = a.geo.k_words / 8;  // k-steps of 256 sites
+  const uint4 *g_rows = a.t2 + (uint64_t)tr * kT;
+  const uint4 *g_cols = a.t2 + a.geo.col_base + (uint64_t)tc * kT;
 
   uint32_t mT;
   asm volatile("s_mov_b32 %0, 0xcccccccc" : "=s"(mT));
 
-  // LDS-DMA: wavefront (side, k-half) fetches that quarter of a stage: 2 slices
-  // x 4 runs of 64 samples, 1 KiB each.  Slice c of k-step s, k-half h is group
-  // 4 s + 2 h + c of the nibble layout (the order of the sites inside k does not
-  // matter as long as rows and columns agree).
+  // LDS-DMA: wavefront (side, k-half) fetches that quarter of a stage: 2 units x
+  // 4 runs of 64 samples, 1 KiB each.  Unit c of k-step s, k-half h is unit
+  // 4 s + 2 h + c of the T2 layout (the order of the sites inside k does not
+  // matter as long as rows and columns agree); every unit feeds TWO slices of 64
+  // sites per k-half: its bits 2-3 (set B) and its bits 0-1 (set A).
   const uint32_t dma_side = wave >> 1, dma_h = wave & 1;
-  const uint32_t row_bytes = s_stride * 16;  // one group of the layout
+  const uint32_t row_bytes = s_stride * 16;  // one unit of the layout
   const char *const g_wave = reinterpret_cast<const char *>(
       (dma_side ? g_cols : g_rows) + (uint64_t)(2 * dma_h) * s_stride);
   const uint32_t l_wave = (uint32_t)(uintptr_t)(lds_void_ptr)(
       lds + ((dma_side * 2 + dma_h) * 2) * kSliceU4);
-  struct Addr { const char *src; uint32_t dst; };  // of slice 0; slice 1: + row_bytes, + 4 KiB
+  struct Addr { const char *src; uint32_t dst; };  // of unit 0; unit 1: + row_bytes, + 4 KiB
   auto addr_of = [&](uint32_t step, uint32_t buf) {
     Addr pa;
     if (step >= num_steps) step = num_steps - 1;  // clamped repeats (see king_mfma.hip)
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
     asm volatile("" : "+s"(pa.src), "+s"(pa.dst));
     return pa;
   };
-  // The four requests of slice c of the stage `pa` names.
+  // The four requests of unit c of the stage `pa` names.
 #define F_ISSUE4(PA, C)                                                        \
   {                                                                            \
     const char *src_ = (PA).src + (C) * row_bytes;                             \
@@ -219,7 +224,8 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
     F_ISSUE4(p0, 0)
     F_ISSUE4(p0, 1)
   }
-  __builtin_amdgcn_s_waitcnt(vmcnt_imm(3 * 8));
+  if (CUKING_FILTER_ABLATE != 1 && CUKING_FILTER_ABLATE != 2)
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(3 * 8));
   __syncthreads();
 
   // This lane's operand words inside a stage (uint4 units).
@@ -227,17 +233,18 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   uint32_t col_off = ((1 * 2 + g) * 2) * kSliceU4 + wx * 128 + lr;
   asm volatile("" : "+v"(row_off), "+v"(col_off), "+v"(lane16));
   v8i FA[2][4], FB[2][4];  // T fragments [slice parity][block]
-  uint4 RAW[8];            // the next slice's words: rows 0-3, columns 4-7
+  uint4 RAW[8];            // the words of one unit: rows 0-3, columns 4-7
 #define F_READ(K, BUF, C)                                                      \
   RAW[K] = lds[(BUF) * kStageU4 + ((K) < 4 ? row_off : col_off) + (C) * kSliceU4 + ((K) & 3) * 32];
-// (plain ANDs: nothing but data orders them against the MFMAs, and left alone
-// the compiler builds every fragment right behind its LDS read, i.e. waits for
-// the read it has just issued.  The empty asm statements tie a build to the
-// place it is written in: not above the pin of its input, not below the pin of
-// its result -- as in king_mfma.hip.)
+// (plain ANDs and shifts: nothing but data orders them against the MFMAs, and
+// left alone the compiler builds every fragment right behind its LDS read, i.e.
+// waits for the read it has just issued.  The empty asm statements tie a build
+// to the place it is written in: not above the pin of its input, not below the
+// pin of its result -- as in king_mfma.hip.)
 #define F_PIN4(W) asm volatile("" : "+v"((W).x), "+v"((W).y), "+v"((W).z), "+v"((W).w));
 #define F_PINF(F) asm volatile("" : "+v"((F)[0]), "+v"((F)[1]), "+v"((F)[2]), "+v"((F)[3]));
-#define F_BUILD(NXT, K)                                                        \
+// Set B of word K: bits 2-3 of every nibble as they are.
+#define F_BUILD_B(NXT, K)                                                      \
   F_PIN4(RAW[K])                                                               \
   if ((K) < 4) {                                                               \
     FA[NXT][(K) & 3] = tfrag(RAW[K], mT);                                      \
@@ -246,65 +253,99 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
     FB[NXT][(K) & 3] = tfrag(RAW[K], mT);                                      \
     F_PINF(FB[NXT][(K) & 3])                                                   \
   }
+// Set A of word K: bits 0-1 moved up to bits 2-3.
+#define F_BUILD_A(NXT, K)                                                      \
+  F_PIN4(RAW[K])                                                               \
+  if ((K) < 4) {                                                               \
+    FA[NXT][(K) & 3] = tfrag(shl2(RAW[K]), mT);                                \
+    F_PINF(FA[NXT][(K) & 3])                                                   \
+  } else {                                                                     \
+    FB[NXT][(K) & 3] = tfrag(shl2(RAW[K]), mT);                                \
+    F_PINF(FB[NXT][(K) & 3])                                                   \
+  }
 #define F_MMA(CUR, BI, BJ) acc[BI][BJ] = mma(FA[CUR][BI], FB[CUR][BJ], acc[BI][BJ]);
-  // One slice of 64 sites.  CUR / NXT: fragment sets of this and the next slice;
-  // (RBUF, RC): stage buffer and slice the next slice's words are read from;
-  // SYNC: stage hand-over first (that read is the first of a new stage);
-  // (PA, DC): the four requests that go out during this slice.
-  // First half: block rows 0-1 with the reads and the requests in the MFMA gaps;
-  // second half: block rows 2-3 with the fragment builds of the next slice.
-#define F_SLICE(CUR, NXT, RBUF, RC, SYNC, PA, DC)                              \
+#define F_BAR __builtin_amdgcn_sched_barrier(0);
+  // Slice B of unit c (fragment set CUR): 16 MFMAs; in their gaps the set-A
+  // fragments of the same words (8 VALU per fragment: every second gap) and two
+  // requests.
+#define F_SLICE_B(CUR, NXT, PA, DC, OFF0, OFF1)                                \
+  {                                                                            \
+    const char *src_ = (PA).src + (DC) * row_bytes;                            \
+    const uint32_t dst_ = (PA).dst + (DC) * (kSliceU4 * 16);                   \
+    F_ISSUE(src_, dst_, OFF0);                                                 \
+    F_MMA(CUR, 0, 0) F_BAR                                                     \
+    F_BUILD_A(NXT, 0) F_MMA(CUR, 0, 1) F_BAR                                   \
+    F_MMA(CUR, 0, 2) F_BAR                                                     \
+    F_BUILD_A(NXT, 1) F_MMA(CUR, 0, 3) F_BAR                                   \
+    F_MMA(CUR, 1, 0) F_BAR                                                     \
+    F_BUILD_A(NXT, 2) F_MMA(CUR, 1, 1) F_BAR                                   \
+    F_MMA(CUR, 1, 2) F_BAR                                                     \
+    F_BUILD_A(NXT, 3) F_MMA(CUR, 1, 3) F_BAR                                   \
+    F_ISSUE(src_, dst_, OFF1);                                                 \
+    F_MMA(CUR, 2, 0) F_BAR                                                     \
+    F_BUILD_A(NXT, 4) F_MMA(CUR, 2, 1) F_BAR                                   \
+    F_MMA(CUR, 2, 2) F_BAR                                                     \
+    F_BUILD_A(NXT, 5) F_MMA(CUR, 2, 3) F_BAR                                   \
+    F_MMA(CUR, 3, 0) F_BAR                                                     \
+    F_BUILD_A(NXT, 6) F_MMA(CUR, 3, 1) F_BAR                                   \
+    F_MMA(CUR, 3, 2) F_BAR                                                     \
+    F_BUILD_A(NXT, 7) F_MMA(CUR, 3, 3) F_BAR                                   \
+  }
+  // Slice A of a unit (fragment set CUR): 16 MFMAs; in the gaps of the first
+  // eight the LDS reads of the NEXT unit's words (RBUF, RC; behind the stage
+  // hand-over if SYNC: that read is the first of a new stage) and two requests,
+  // in the gaps of the last eight that unit's set-B fragments.
+#define F_SLICE_A(CUR, NXT, RBUF, RC, SYNC, PA, DC, OFF0, OFF1)                \
   {                                                                            \
     if ((SYNC) && CUKING_FILTER_ABLATE != 2) {                                 \
-      __builtin_amdgcn_s_waitcnt(vmcnt_imm(2 * 8 + 4));                        \
+      if (CUKING_FILTER_ABLATE != 1) __builtin_amdgcn_s_waitcnt(vmcnt_imm(2 * 8 + 6)); \
       __syncthreads();                                                         \
     }                                                                          \
     const char *src_ = (PA).src + (DC) * row_bytes;                            \
     const uint32_t dst_ = (PA).dst + (DC) * (kSliceU4 * 16);                   \
     F_READ(0, RBUF, RC) F_READ(1, RBUF, RC)                                    \
-    F_ISSUE(src_, dst_, 0);                                                    \
-    F_MMA(CUR, 0, 0) F_MMA(CUR, 0, 1)                                          \
-    __builtin_amdgcn_sched_barrier(0);                                         \
+    F_ISSUE(src_, dst_, OFF0);                                                 \
+    F_MMA(CUR, 0, 0) F_MMA(CUR, 0, 1) F_BAR                                    \
     F_READ(2, RBUF, RC) F_READ(3, RBUF, RC)                                    \
-    F_ISSUE(src_, dst_, 1024);                                                 \
-    F_MMA(CUR, 0, 2) F_MMA(CUR, 0, 3)                                          \
-    __builtin_amdgcn_sched_barrier(0);                                         \
+    F_MMA(CUR, 0, 2) F_MMA(CUR, 0, 3) F_BAR                                    \
     F_READ(4, RBUF, RC) F_READ(5, RBUF, RC)                                    \
-    F_ISSUE(src_, dst_, 2048);                                                 \
-    F_MMA(CUR, 1, 0) F_MMA(CUR, 1, 1)                                          \
-    __builtin_amdgcn_sched_barrier(0);                                         \
+    F_ISSUE(src_, dst_, OFF1);                                                 \
+    F_MMA(CUR, 1, 0) F_MMA(CUR, 1, 1) F_BAR                                    \
     F_READ(6, RBUF, RC) F_READ(7, RBUF, RC)                                    \
-    F_ISSUE(src_, dst_, 3072);                                                 \
-    F_MMA(CUR, 1, 2) F_MMA(CUR, 1, 3)                                          \
-    __builtin_amdgcn_sched_barrier(0);                                         \
-    F_BUILD(NXT, 0) F_MMA(CUR, 2, 0) __builtin_amdgcn_sched_barrier(0);        \
-    F_BUILD(NXT, 1) F_MMA(CUR, 2, 1) __builtin_amdgcn_sched_barrier(0);        \
-    F_BUILD(NXT, 2) F_MMA(CUR, 2, 2) __builtin_amdgcn_sched_barrier(0);        \
-    F_BUILD(NXT, 3) F_MMA(CUR, 2, 3) __builtin_amdgcn_sched_barrier(0);        \
-    F_BUILD(NXT, 4) F_MMA(CUR, 3, 0) __builtin_amdgcn_sched_barrier(0);        \
-    F_BUILD(NXT, 5) F_MMA(CUR, 3, 1) __builtin_amdgcn_sched_barrier(0);        \
-    F_BUILD(NXT, 6) F_MMA(CUR, 3, 2) __builtin_amdgcn_sched_barrier(0);        \
-    F_BUILD(NXT, 7) F_MMA(CUR, 3, 3) __builtin_amdgcn_sched_barrier(0);        \
+    F_MMA(CUR, 1, 2) F_MMA(CUR, 1, 3) F_BAR                                    \
+    F_BUILD_B(NXT, 0) F_MMA(CUR, 2, 0) F_BAR                                   \
+    F_BUILD_B(NXT, 1) F_MMA(CUR, 2, 1) F_BAR                                   \
+    F_BUILD_B(NXT, 2) F_MMA(CUR, 2, 2) F_BAR                                   \
+    F_BUILD_B(NXT, 3) F_MMA(CUR, 2, 3) F_BAR                                   \
+    F_BUILD_B(NXT, 4) F_MMA(CUR, 3, 0) F_BAR                                   \
+    F_BUILD_B(NXT, 5) F_MMA(CUR, 3, 1) F_BAR                                   \
+    F_BUILD_B(NXT, 6) F_MMA(CUR, 3, 2) F_BAR                                   \
+    F_BUILD_B(NXT, 7) F_MMA(CUR, 3, 3) F_BAR                                   \
   }
 
-  // slice 0 of stage 0
+  // unit 0 of stage 0, set B
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     F_READ(k, 0, 0)
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    F_BUILD(0, k)
+    F_BUILD_B(0, k)
   }
   uint32_t buf = 0;  // buffer of the k-step being multiplied
   // k-step s requests stage s + 4 into the buffer stage s - 1 left: every
-  // wavefront finished reading it before the hand-over of k-step s - 1.
+  // wavefront finished reading it before the hand-over of k-step s - 1.  The
+  // hand-over of k-step s (stage s + 1 must have landed) comes in its last slice:
+  // in flight then may be stages s + 2, s + 3 and the six requests of stage s + 4
+  // that the first three slices issued.
   Addr pa = addr_of(kStages - 1, kStages - 1);
 #define F_KSTEP                                                                \
   {                                                                            \
     const uint32_t nbuf = buf == kStages - 1 ? 0 : buf + 1;                    \
-    F_SLICE(0, 1, buf, 1, false, pa, 0)                                        \
-    F_SLICE(1, 0, nbuf, 0, true, pa, 1)                                        \
+    F_SLICE_B(0, 1, pa, 0, 0, 1024)                                            \
+    F_SLICE_A(1, 0, buf, 1, false, pa, 0, 2048, 3072)                          \
+    F_SLICE_B(0, 1, pa, 1, 0, 1024)                                            \
+    F_SLICE_A(1, 0, nbuf, 0, true, pa, 1, 2048, 3072)                          \
     pa = addr_next(pa, step + kStages, buf);                                   \
     buf = nbuf;                                                                \
     ++step;                                                                    \
@@ -316,9 +357,12 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   }
   if (step < num_steps) F_KSTEP
 #undef F_KSTEP
-#undef F_SLICE
+#undef F_SLICE_A
+#undef F_SLICE_B
+#undef F_BAR
 #undef F_MMA
-#undef F_BUILD
+#undef F_BUILD_A
+#undef F_BUILD_B
 #undef F_PIN4
 #undef F_PINF
 #undef F_READ
@@ -362,16 +406,20 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   uint32_t total = 0, base = 0, run = 0;  // wave-uniform
 #pragma nounroll
   for (int pass = 0; pass < 2; ++pass) {  // 0: count the candidates, 1: append them
+    // (opaque per pass: otherwise the compiler computes the 256 pairs' indices and
+    //  validity once in front of the loop and parks them in scratch memory)
+    uint32_t tr_p = tr, tc_p = tc;
+    asm volatile("" : "+s"(tr_p), "+s"(tc_p));
 #pragma unroll
     for (int bi = 0; bi < 4; ++bi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const uint32_t row = wy * 128 + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
         const float2 sr = st_rows[row];
-        const uint32_t li = tr * kT + row;
+        const uint32_t li = tr_p * kT + row;
 #pragma unroll
         for (int bj = 0; bj < 4; ++bj) {
-          const uint32_t lj = tc * kT + wx * 128 + bj * 32 + lr;
+          const uint32_t lj = tc_p * kT + wx * 128 + bj * 32 + lr;
           // cuking.cu:199 plus the tile padding
           const bool valid = li < a.geo.num_rows && lj < a.geo.num_cols &&
                              a.i_begin + li < a.j_begin + lj;
