@@ -322,6 +322,14 @@ def roofline_block(args, ctx, *, launch_pairs, sites, wps, thr, king_ms, prepare
     return roofline
 
 
+def filter_counters(ctx):
+    """(candidates, dense quadrants) so far, or None when the context's variant is not
+    the filter variant (diagnostic options of the library: they wait for the device)."""
+    if ctx.get_option("variant") != 7:
+        return None
+    return ctx.get_option("filter_candidates"), ctx.get_option("filter_dense_quadrants")
+
+
 def records_of(results, count):
     import numpy as np
     import cuking_amd
@@ -372,12 +380,14 @@ def single_gpu_workload(args, ctx, n, m, thr, steps, warmup, local_rank, clock_p
     torch.cuda.synchronize()
     warm = ctx.timing_collect()
     ctx.timing_reset()
+    filt0 = filter_counters(ctx)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timing = ctx.timing_collect()
+    filt1 = filter_counters(ctx)
     count, ovf = index_flag.tolist()
     if ovf:
         raise SystemExit("result overflow: raise --max-results")
@@ -402,7 +412,14 @@ def single_gpu_workload(args, ctx, n, m, thr, steps, warmup, local_rank, clock_p
                 prepare_ms=prep.prepare_ms / max(prep.prepare_launches, 1),
                 prepare_launches_timed=timing.prepare_launches,
                 launches=timing.king_launches, recs=recs, bits=bits, cohort=cohort,
-                clock_mhz=clock)
+                clock_mhz=clock,
+                filter=(None if filt0 is None else
+                        {"candidates_per_pass": (filt1[0] - filt0[0]) / steps,
+                         "dense_quadrants_per_pass": (filt1[1] - filt0[1]) / steps,
+                         "records_per_pass": len(recs),
+                         "note": "filter variant: pairs its bound let through to the exact "
+                                 "recount, 128 x 128 quadrants handed to the four-product "
+                                 "kernel instead, and the records of a pass"}))
 
 
 def dist_workload(args, env, ctx, key, n, m, thr, steps, warmup, headline):
@@ -761,6 +778,8 @@ def main():
             args, ctx, launch_pairs=r["pairs"], sites=m, wps=r["wps"], thr=thr,
             king_ms=r["king_ms"], prepare_ms=r["prepare_ms"], launches=r["launches"],
             workload_key=f"{n}x{m}", clock_mhz=r["clock_mhz"])
+        if r["filter"] is not None:
+            roofline["filter"] = r["filter"]
         out = {
             "metric": "sample-pairs/s (all-pairs KING)",
             "value": r["pairs"] * args.steps / r["elapsed"],
@@ -802,6 +821,8 @@ def main():
                 thr=c["thr"], king_ms=e["king_ms"], prepare_ms=e["prepare_ms"],
                 launches=e["launches"], workload_key=f"{c['samples']}x{c['sites']}",
                 clock_mhz=e["clock_mhz"])
+            if e["filter"] is not None:
+                roof["filter"] = e["filter"]
             others[key] = {
                 "workload": c["name"] + ", on ONE GPU", "value": e["pairs"] * k / e["elapsed"],
                 "unit": "sample-pairs/s", "steps": k, "warmup": w,
@@ -811,7 +832,8 @@ def main():
                 "checks": "planted relatives all reported",
                 "roofline": {kk: roof[kk] for kk in
                              ("bound", "achieved", "peak", "unit", "frac", "kernel_ms",
-                              "prepare_ms", "sustained_clock_mhz", "form")
+                              "prepare_ms", "sustained_clock_mhz", "form", "kernel",
+                              "macs_per_pair_site", "filter")
                              if kk in roof},
             }
             del e

@@ -319,6 +319,12 @@ cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const Plan
     }
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base), filter_scratch_bytes()));
     ++ctx->workspace_allocations;
+    // (the running totals behind "filter_candidates" / "filter_dense_quadrants")
+    hipError_t e = hipMemsetAsync(base, 0, kFilterCtrlBytes, stream);
+    if (e != hipSuccess) {
+      (void)hipFree(base);
+      HIP_TRY(e);
+    }
     ctx->filter_scratch.emplace_back(stream, base);
   }
   a->sample_stats = plane_stats(ctx->planes, geo);
@@ -979,6 +985,22 @@ cuking_status cuking_ctx_get_option(const cuking_ctx *ctx, const char *key,
   else if (strcmp(key, "reuse_prepared") == 0) *value = ctx->reuse_prepared ? 1 : 0;
   else if (strcmp(key, "filter_quadrant_cap") == 0) *value = ctx->filter_quadrant_cap;
   else if (strcmp(key, "filter_cand_cap") == 0) *value = ctx->filter_cand_cap;
+  else if (strcmp(key, "filter_candidates") == 0 || strcmp(key, "filter_dense_quadrants") == 0) {
+    // Diagnostics (they WAIT for the device): pairs the bound let through and
+    // quadrants handed to the exact kernel, summed over the context's streams,
+    // since the scratch was allocated.
+    const size_t word = strcmp(key, "filter_candidates") == 0 ? 2 : 3;  // (u64 words)
+    unsigned long long total = 0;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+      return cuking_fail(CUKING_ERR_DEVICE, "device wait failed");
+    for (auto &e : ctx->filter_scratch) {
+      unsigned long long v = 0;
+      if (hipMemcpy(&v, e.second + word * 8, 8, hipMemcpyDeviceToHost) != hipSuccess)
+        return cuking_fail(CUKING_ERR_DEVICE, "reading the filter counters failed");
+      total += v;
+    }
+    *value = (int64_t)total;
+  }
   else if (strcmp(key, "workspace_allocations") == 0) *value = (int64_t)ctx->workspace_allocations;
   else if (strcmp(key, "host_syncs") == 0) *value = (int64_t)ctx->host_syncs;
   else if (strcmp(key, "conversions_skipped") == 0) *value = (int64_t)ctx->conversions_skipped;

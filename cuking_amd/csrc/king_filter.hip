@@ -143,7 +143,21 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   extern __shared__ uint4 lds[];  // [kStages][side][k-half][slice][256]
 
   uint32_t bid = blockIdx.x;
-  if (a.xcd_chunk == 1) {
+  if (a.dyn_tiles != 0 && blockIdx.x >= a.launch_tiles) {
+    // dynamic tail (king_common.h): the next of the launch's last dyn_tiles tiles
+    // nobody has taken yet -- the XCDs run at rates a few percent apart, and an
+    // XCD that gets through its static share early takes more of these.  (The
+    // counter is filter_ctrl[2], zeroed in front of every launch.)
+    uint32_t *slot = reinterpret_cast<uint32_t *>(lds);
+    if (threadIdx.x == 0)
+      *slot = __hip_atomic_fetch_add(a.filter_ctrl + 2, 1u, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const uint32_t t = __builtin_amdgcn_readfirstlane(*slot);
+    __syncthreads();  // the word is stage memory from here on
+    if (t >= a.dyn_tiles) return;  // uniform
+    bid = a.launch_tiles + t;
+  } else if (a.xcd_chunk == 1) {
     // patches of 32 consecutive tiles dealt round-robin to the XCDs (king_common.h)
     const uint32_t x = bid & 7, j = bid >> 3;
     bid = (((j >> 5) * 8 + x) << 5) + (j & 31);
@@ -445,9 +459,14 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
       bool dense = total > a.quadrant_cap;
       if (!dense) {
         uint32_t got = 0;
-        if (lane == 0)
+        if (lane == 0) {
           got = __hip_atomic_fetch_add(a.filter_ctrl, total, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
+          // (running total since the scratch was allocated: "filter_candidates")
+          __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.filter_ctrl + 4),
+                                 (unsigned long long)total, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+        }
         base = (uint32_t)__builtin_amdgcn_readfirstlane(got);
         if (base >= a.cand_cap || total > a.cand_cap - base) {
           // list full: the slots taken (if any) must not be read as pairs
@@ -461,6 +480,8 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
           const uint32_t slot = __hip_atomic_fetch_add(a.filter_ctrl + 1, 1u, __ATOMIC_RELAXED,
                                                        __HIP_MEMORY_SCOPE_AGENT);
           if (slot < a.dense_cap) a.dense_list[slot] = make_uint2(2 * tr + wy, 2 * tc + wx);
+          __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.filter_ctrl + 6), 1ull,
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         break;
       }
@@ -570,7 +591,18 @@ hipError_t launch_filter(const TiledArgs &args, uint64_t num_tiles, hipStream_t 
     a.quad = 0;
     a.tile_list = nullptr;
     uint64_t grid = n;
-    if (args.xcd_chunk == 2 && n >= 64) {  // patches of 32, dealt round-robin to the XCDs
+    a.dyn_tiles = a.dyn_wgs = 0;
+    if (args.xcd_chunk == 2 && args.dyn_tiles != 0 && n >= args.dyn_tiles / 4 && n >= 288) {
+      // whole rounds of patches, then the last ~6 % through the counter with half
+      // as many workgroups again as tiles (launch_shape in king_mfma.hip; the
+      // threshold is the context's, in 128-sample tiles there)
+      const uint64_t fixed = (n - n / 16) / 256 * 256;
+      a.launch_tiles = (uint32_t)fixed;
+      a.xcd_chunk = 1;
+      a.dyn_tiles = (uint32_t)(n - fixed);
+      a.dyn_wgs = a.dyn_tiles + a.dyn_tiles / 2;
+      grid = fixed + a.dyn_wgs;
+    } else if (args.xcd_chunk == 2 && n >= 64) {  // patches of 32, dealt round-robin to the XCDs
       a.launch_tiles = (uint32_t)n;
       a.xcd_chunk = 1;
       grid = 8ull * 32 * ((((n + 31) / 32) + 7) / 8);

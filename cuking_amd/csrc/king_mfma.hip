@@ -1731,9 +1731,25 @@ hipError_t launch_mfma_list(const TiledArgs &args, uint32_t grid, hipStream_t st
   a.rect_rows = 0;
   a.split_tiles = a.split_whole = 0;
   a.split_scratch = a.split_counters = nullptr;
-  a.xcd_chunk = 0;  // (launch_shape: plain order, no dynamic tail)
+  a.xcd_chunk = 0;  // plain order, no dynamic tail
   a.dyn_tiles = a.dyn_wgs = 0;
-  return launch_shape<false, false, 0, true>(a, grid, kMfmaN4LdsBytes, stream);
+  a.launch_tiles = 0;
+  // ONE launch whatever the block limit (a test hook may set it below `grid`): the
+  // workgroups stride over the list, a second launch would walk it again.
+  const uint64_t cap = max_blocks_per_launch(256);
+  if (grid > cap) grid = (uint32_t)cap;
+  if (grid == 0) return hipErrorInvalidValue;
+  auto kernel = king_mfma_kernel<false, false, 0, true>;
+  static DeviceOnce attr_set;  // per device, see king_device.h
+  if (!attr_set.done()) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)kMfmaN4LdsBytes);
+    if (e != hipSuccess) return e;
+    attr_set.mark();
+  }
+  kernel<<<dim3(grid), dim3(256), kMfmaN4LdsBytes, stream>>>(a);
+  return hipGetLastError();
 }
 
 hipError_t launch_mfma(bool full, bool nibble, const TiledArgs &args, uint64_t num_tiles,

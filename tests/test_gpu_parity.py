@@ -1028,7 +1028,7 @@ def test_wide_pair_with_4opp_beyond_2_24_on_the_gpu(ctx, kernel, variant):
 
 def test_reserved_workspace_means_no_allocation_and_no_host_wait(oracle):
     """cuking_ctx_reserve sizes the kernel layout, the tile prefix and the named
-    streams' split slabs up front; the compute / prepare calls for the block on
+    streams' split slabs and filter scratch up front; the compute / prepare calls for the block on
     those streams then allocate nothing and never wait for the device (what a
     host needs once collectives are in flight: host/multi_gpu.cc)."""
     import torch
@@ -1048,7 +1048,7 @@ def test_reserved_workspace_means_no_allocation_and_no_host_wait(oracle):
         assert c.get_option("workspace_allocations") == 0
         c.reserve(sm, wps, streams)
         a0, s0 = c.get_option("workspace_allocations"), c.get_option("host_syncs")
-        assert a0 == 4                      # layout, prefix table, two slabs
+        assert a0 == 6                      # layout, prefix table, two split slabs, two filter scratch sets
         c.reserve(sm, wps, streams)         # idempotent
         assert c.get_option("workspace_allocations") == a0
         results = torch.zeros((len(exp) + 8, 6), dtype=torch.int32, device="cuda:0")
