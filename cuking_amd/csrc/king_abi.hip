@@ -115,6 +115,7 @@ struct cuking_ctx {
   std::vector<std::pair<hipStream_t, uint8_t *>> filter_scratch;
   uint32_t filter_quadrant_cap = kFilterQuadrantCap;
   uint32_t filter_cand_cap = kFilterCandCap;
+  uint32_t filter_split_min_steps = 8;  // k-steps per remainder piece, at least
 
   // What the plane workspace holds: the block it was converted for and which
   // 64-sample plane tiles of it have been converted (cuking_compute_king_rect
@@ -306,6 +307,9 @@ cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const Plan
   a->cand_list = nullptr;
   a->dense_list = nullptr;
   a->cand_cap = a->dense_cap = a->quadrant_cap = 0;
+  a->fsplit_parts = a->fsplit_first = a->fsplit_tile0 = 0;
+  a->fsplit_slabs = nullptr;
+  a->fsplit_tickets = nullptr;
   if (ctx->variant != kMfmaFilterVariant) return CUKING_OK;
   uint8_t *base = nullptr;
   for (auto &e : ctx->filter_scratch)
@@ -320,7 +324,8 @@ cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const Plan
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base), filter_scratch_bytes()));
     ++ctx->workspace_allocations;
     // (the running totals behind "filter_candidates" / "filter_dense_quadrants")
-    hipError_t e = hipMemsetAsync(base, 0, kFilterCtrlBytes, stream);
+    // ... and the tickets of the remainder pieces, zero between launches
+    hipError_t e = hipMemsetAsync(base, 0, kFilterCtrlBytes + kFilterTicketBytes, stream);
     if (e != hipSuccess) {
       (void)hipFree(base);
       HIP_TRY(e);
@@ -330,11 +335,17 @@ cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const Plan
   a->sample_stats = plane_stats(ctx->planes, geo);
   a->t2 = plane_t2(ctx->planes, geo);
   a->filter_ctrl = reinterpret_cast<uint32_t *>(base);
-  a->cand_list = reinterpret_cast<uint2 *>(base + kFilterCtrlBytes);
+  a->fsplit_tickets = reinterpret_cast<uint32_t *>(base + kFilterCtrlBytes);
+  a->cand_list = reinterpret_cast<uint2 *>(base + kFilterCtrlBytes + kFilterTicketBytes);
   a->cand_cap = ctx->filter_cand_cap;
   a->quadrant_cap = ctx->filter_quadrant_cap;
   a->dense_list = a->cand_list + kFilterCandCap;
   a->dense_cap = kFilterChunkTiles * 4;
+  // (remainder splitting follows the matrix-core kernels' switch: "split_wgs" 0 = never)
+  a->fsplit_first = ctx->filter_split_min_steps;  // (on entry: launch_filter)
+  a->fsplit_slabs = ctx->split_wgs != 0
+                        ? reinterpret_cast<float4 *>(a->dense_list + (size_t)kFilterChunkTiles * 4)
+                        : nullptr;
   return CUKING_OK;
 }
 
@@ -753,6 +764,12 @@ cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
     ctx->filter_quadrant_cap = (uint32_t)value;
     return CUKING_OK;
   }
+  if (strcmp(key, "filter_split_min_steps") == 0) {  // tests: remainder pieces of short bitsets
+    if (value < 1 || value > 4096)
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "filter_split_min_steps outside [1, 4096]");
+    ctx->filter_split_min_steps = (uint32_t)value;
+    return CUKING_OK;
+  }
   if (strcmp(key, "filter_cand_cap") == 0) {  // tests: a short candidate list
     if (value < 0 || value > (int64_t)kFilterCandCap)
       return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "filter_cand_cap outside [0, %u]", kFilterCandCap);
@@ -985,6 +1002,7 @@ cuking_status cuking_ctx_get_option(const cuking_ctx *ctx, const char *key,
   else if (strcmp(key, "reuse_prepared") == 0) *value = ctx->reuse_prepared ? 1 : 0;
   else if (strcmp(key, "filter_quadrant_cap") == 0) *value = ctx->filter_quadrant_cap;
   else if (strcmp(key, "filter_cand_cap") == 0) *value = ctx->filter_cand_cap;
+  else if (strcmp(key, "filter_split_min_steps") == 0) *value = ctx->filter_split_min_steps;
   else if (strcmp(key, "filter_candidates") == 0 || strcmp(key, "filter_dense_quadrants") == 0) {
     // Diagnostics (they WAIT for the device): pairs the bound let through and
     // quadrants handed to the exact kernel, summed over the context's streams,

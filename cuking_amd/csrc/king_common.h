@@ -196,6 +196,14 @@ struct TiledArgs {
   uint32_t quadrant_cap;   // candidates per quadrant beyond which it is "dense"
   uint2 *dense_list;
   uint32_t dense_cap;
+  // Filter kernel, remainder of a short launch (king_filter.hip): workgroups from
+  // fsplit_first on take ONE of fsplit_parts equal pieces of the k range of tile
+  // fsplit_tile0 + (index - fsplit_first) / fsplit_parts of the launch; a piece
+  // parks its sums in its slab, and the workgroup that delivers a tile's last
+  // piece adds the others to its own (tickets: zero between launches).
+  uint32_t fsplit_parts, fsplit_first, fsplit_tile0;
+  float4 *fsplit_slabs;
+  uint32_t *fsplit_tickets;
 };
 
 // Bytes of the plane workspace for a geometry.
@@ -256,11 +264,21 @@ static_assert(kFilterLdsBytes <= 160 * 1024, "LDS of one CU");
 // Per launch chunk: at most this many 256-tiles (bounds the dense-quadrant list).
 constexpr uint32_t kFilterChunkTiles = 1u << 17;
 constexpr uint32_t kFilterCandCap = 1u << 20;      // candidate pairs per chunk
-constexpr uint32_t kFilterQuadrantCap = 1024;      // candidates per 128 x 128 quadrant
+// Candidates per 128 x 128 quadrant beyond which the quadrant goes to the exact
+// kernel: one wavefront per candidate costs 3.4 ns of chip time at 100k sites
+// (1.65 M candidates in 5.6 ms), the four-product kernel 1.85 us per quadrant --
+// break-even near 540, whatever the site count (both are linear in it;
+// profiles/r03_filter_curve.txt).
+constexpr uint32_t kFilterQuadrantCap = 384;
 constexpr size_t kFilterCtrlBytes = 256;
+// Remainder splitting: at most this many pieces per launch (one per CU), a slab of
+// 256 x 256 float sums and a ticket word each.
+constexpr uint32_t kFilterSplitSlabs = 256;
+constexpr size_t kFilterSlabBytes = 256 * 256 * sizeof(float);
+constexpr size_t kFilterTicketBytes = kFilterSplitSlabs * sizeof(uint32_t);
 inline size_t filter_scratch_bytes() {
-  return kFilterCtrlBytes + (size_t)kFilterCandCap * sizeof(uint2) +
-         (size_t)kFilterChunkTiles * 4 * sizeof(uint2);
+  return kFilterCtrlBytes + kFilterTicketBytes + (size_t)kFilterCandCap * sizeof(uint2) +
+         (size_t)kFilterChunkTiles * 4 * sizeof(uint2) + kFilterSplitSlabs * kFilterSlabBytes;
 }
 inline bool is_mfma_variant(int v) {
   return v == kMfmaVariant || v == kMfmaN4Variant || v == kMfmaFilterVariant;

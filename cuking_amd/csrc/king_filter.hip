@@ -143,6 +143,15 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   extern __shared__ uint4 lds[];  // [kStages][side][k-half][slice][256]
 
   uint32_t bid = blockIdx.x;
+  // Remainder of a short launch (king_common.h, fsplit_*): piece `part` of the k
+  // range of one of the launch's last tiles.
+  const bool split = a.fsplit_parts != 0 && blockIdx.x >= a.fsplit_first;
+  uint32_t part = 0, piece = 0;
+  if (split) {
+    piece = blockIdx.x - a.fsplit_first;
+    part = __builtin_amdgcn_readfirstlane(piece % a.fsplit_parts);
+    bid = a.fsplit_tile0 + piece / a.fsplit_parts;
+  } else
   if (a.dyn_tiles != 0 && blockIdx.x >= a.launch_tiles) {
     // dynamic tail (king_common.h): the next of the launch's last dyn_tiles tiles
     // nobody has taken yet -- the XCDs run at rates a few percent apart, and an
@@ -172,11 +181,41 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t wy = wave >> 1, wx = wave & 1;  // the wavefront's quadrant
+  // When the bound does not thin this cohort out (a threshold inside the noise of
+  // unrelated pairs, heavy missingness) nearly every quadrant ends on the dense list
+  // anyway: once most of at least 512 finished quadrants of the launch have, the
+  // remaining tiles skip the product and hand their quadrants over directly, so the
+  // worst case costs the exact kernel's time plus the first round of this one
+  // (filter_ctrl[1] dense quadrants, [3] quadrants finished; both per launch).
+  if (!split) {
+    const uint32_t dense_so_far = __hip_atomic_load(a.filter_ctrl + 1, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t finished = __hip_atomic_load(a.filter_ctrl + 3, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+    if (finished >= 512 && 2 * dense_so_far > finished) {  // uniform
+      if (lane == 0 && !(a.tiles.diag && 2 * tc + wx < 2 * tr + wy)) {
+        const uint32_t slot = __hip_atomic_fetch_add(a.filter_ctrl + 1, 1u, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+        if (slot < a.dense_cap) a.dense_list[slot] = make_uint2(2 * tr + wy, 2 * tc + wx);
+        __hip_atomic_fetch_add(a.filter_ctrl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.filter_ctrl + 6), 1ull,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+  }
   const uint32_t g = lane >> 5;                  // k-half of the MFMA operand
   const uint32_t lr = lane & 31;                 // row / column inside a block
   uint32_t lane16 = lane * 16;
   const uint32_t s_stride = a.geo.s_stride;
-  const uint32_t num_steps = a.geo.k_words / 8;  // k-steps of 256 sites
+  // k-steps of 256 sites: all of them, or this piece's share
+  const uint32_t all_steps = a.geo.k_words / 8;
+  // (wave-uniform, but divisions run in vector registers: pinned to SGPRs for the
+  //  request addresses)
+  const uint32_t k_first = __builtin_amdgcn_readfirstlane(
+      split ? part * all_steps / a.fsplit_parts : 0u);
+  const uint32_t num_steps = __builtin_amdgcn_readfirstlane(
+      split ? (part + 1) * all_steps / a.fsplit_parts - k_first : all_steps);
   const uint4 *g_rows = a.t2 + (uint64_t)tr * kT;
   const uint4 *g_cols = a.t2 + a.geo.col_base + (uint64_t)tc * kT;
 
@@ -191,7 +230,7 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   const uint32_t dma_side = wave >> 1, dma_h = wave & 1;
   const uint32_t row_bytes = s_stride * 16;  // one unit of the layout
   const char *const g_wave = reinterpret_cast<const char *>(
-      (dma_side ? g_cols : g_rows) + (uint64_t)(2 * dma_h) * s_stride);
+      (dma_side ? g_cols : g_rows) + ((uint64_t)4 * k_first + 2 * dma_h) * s_stride);
   const uint32_t l_wave = (uint32_t)(uintptr_t)(lds_void_ptr)(
       lds + ((dma_side * 2 + dma_h) * 2) * kSliceU4);
   struct Addr { const char *src; uint32_t dst; };  // of unit 0; unit 1: + row_bytes, + 4 KiB
@@ -387,6 +426,70 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __syncthreads();
 
+  if (split) {
+    // Park this piece (16-byte write-through stores, [4 registers][thread]), take
+    // a ticket of the tile; the last piece in adds the others to its own.
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    constexpr uint32_t kSlabU4 = 64 * 256;  // float4 per slab
+    {
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          a.fsplit_slabs + (size_t)piece * kSlabU4, 0, (int)(kSlabU4 * 16), 0x00020000);
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            v4u v;
+            v[0] = __float_as_uint(acc[bi][bj][4 * r4]);
+            v[1] = __float_as_uint(acc[bi][bj][4 * r4 + 1]);
+            v[2] = __float_as_uint(acc[bi][bj][4 * r4 + 2]);
+            v[3] = __float_as_uint(acc[bi][bj][4 * r4 + 3]);
+            __builtin_amdgcn_raw_buffer_store_b128(
+                v, rsrc, (int)((((bi * 4 + bj) * 4 + r4) * 256 + threadIdx.x) * 16), 0,
+                16 /* sc1 */);
+          }
+    }
+    // every wavefront's stores are done (and written through), then the ticket
+    // (cdna_hip_programming.md, Guideline 16: sc1 payload + counter)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint32_t *flag = reinterpret_cast<uint32_t *>(lds);  // the stages are idle now
+    if (threadIdx.x == 0) {
+      uint32_t *counter = a.fsplit_tickets + piece / a.fsplit_parts;
+      const uint32_t ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+      const bool last = ticket == a.fsplit_parts - 1;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *counter = 0;  // ready for the next launch
+      }
+      *flag = last ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool last = *flag != 0;
+    __syncthreads();  // (the flag word becomes the epilogue's scratch)
+    if (!last) return;
+    const uint32_t first_piece = piece - part;
+    for (uint32_t p = 0; p < a.fsplit_parts; ++p) {
+      if (p == part) continue;
+      const float4 *src = a.fsplit_slabs + (size_t)(first_piece + p) * kSlabU4 + threadIdx.x;
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const float4 v = src[((bi * 4 + bj) * 4 + r4) * 256];
+            acc[bi][bj][4 * r4] += v.x;
+            acc[bi][bj][4 * r4 + 1] += v.y;
+            acc[bi][bj][4 * r4 + 2] += v.z;
+            acc[bi][bj][4 * r4 + 3] += v.w;
+          }
+    }
+  }
+
   if (CUKING_FILTER_ABLATE != 0) {
     float sum = 0.f;
 #pragma unroll
@@ -416,6 +519,31 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   float2 sc[4];
 #pragma unroll
   for (int bj = 0; bj < 4; ++bj) sc[bj] = st_cols[wx * 128 + bj * 32 + lr];
+
+  // Nearly every wavefront has no candidate at all: a first sweep with the bare test
+  // (5 VALU per pair, the largest `bound - x_lb` of the lane: positive <=> the test
+  // below holds for some pair, the sign of a float difference is exact; pairs outside
+  // the block may raise a false alarm, which only costs the sweeps below), then out.
+  {
+    float best = -1.f;
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float2 sr = st_rows[wy * 128 + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * g];
+#pragma unroll
+        for (int bj = 0; bj < 4; ++bj)
+          best = fmaxf(best, fminf(sr.y, sc[bj].y) -
+                                 fmaf(-0.5f, acc[bi][bj][r], sr.x + sc[bj].x));
+      }
+    if (__ballot(best > 0.f) == 0) {  // wave-uniform
+      if (lane == 0)
+        __hip_atomic_fetch_add(a.filter_ctrl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
+  if (lane == 0)
+    __hip_atomic_fetch_add(a.filter_ctrl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   uint32_t total = 0, base = 0, run = 0;  // wave-uniform
 #pragma nounroll
@@ -590,25 +718,50 @@ hipError_t launch_filter(const TiledArgs &args, uint64_t num_tiles, hipStream_t 
     a.tile_begin = args.tile_begin + done;
     a.quad = 0;
     a.tile_list = nullptr;
-    uint64_t grid = n;
+    // Short launches: the tiles beyond whole rounds of one per CU would leave most
+    // CUs idle for a whole tile time; each of them is cut into `parts` pieces of k
+    // instead (same launch, behind the whole tiles).
+    uint32_t rest = 0, parts = 0;
+    if (args.fsplit_slabs != nullptr && args.fsplit_tickets != nullptr && n < 16ull * wgs) {
+      rest = (uint32_t)(n % wgs);
+      if (rest != 0 && 2 * rest <= wgs && rest <= kFilterSplitSlabs / 2) {
+        parts = wgs / rest;
+        if (parts > 8) parts = 8;
+        if (parts * rest > kFilterSplitSlabs) parts = kFilterSplitSlabs / rest;
+        // (pieces of at least 8 k-steps -- on entry args.fsplit_first, a test hook --:
+        //  the pipeline's fill and the slab are per piece)
+        const uint32_t min_steps = args.fsplit_first != 0 ? args.fsplit_first : 8;
+        while (parts > 1 && args.geo.k_words / 8 / parts < min_steps) --parts;
+      }
+      if (parts < 2) rest = parts = 0;
+    }
+    const uint64_t n_whole = n - rest;  // tiles that go out whole
+    uint64_t grid = n_whole;
     a.dyn_tiles = a.dyn_wgs = 0;
-    if (args.xcd_chunk == 2 && args.dyn_tiles != 0 && n >= args.dyn_tiles / 4 && n >= 288) {
+    if (args.xcd_chunk == 2 && args.dyn_tiles != 0 && n_whole >= args.dyn_tiles / 4 &&
+        n_whole >= 288) {
       // whole rounds of patches, then the last ~6 % through the counter with half
       // as many workgroups again as tiles (launch_shape in king_mfma.hip; the
       // threshold is the context's, in 128-sample tiles there)
-      const uint64_t fixed = (n - n / 16) / 256 * 256;
+      const uint64_t fixed = (n_whole - n_whole / 16) / 256 * 256;
       a.launch_tiles = (uint32_t)fixed;
       a.xcd_chunk = 1;
-      a.dyn_tiles = (uint32_t)(n - fixed);
+      a.dyn_tiles = (uint32_t)(n_whole - fixed);
       a.dyn_wgs = a.dyn_tiles + a.dyn_tiles / 2;
       grid = fixed + a.dyn_wgs;
-    } else if (args.xcd_chunk == 2 && n >= 64) {  // patches of 32, dealt round-robin to the XCDs
-      a.launch_tiles = (uint32_t)n;
+    } else if (args.xcd_chunk == 2 && n_whole >= 64) {  // patches of 32, dealt round-robin to the XCDs
+      a.launch_tiles = (uint32_t)n_whole;
       a.xcd_chunk = 1;
-      grid = 8ull * 32 * ((((n + 31) / 32) + 7) / 8);
+      grid = 8ull * 32 * ((((n_whole + 31) / 32) + 7) / 8);
     } else {
       a.xcd_chunk = 0;
+      a.launch_tiles = (uint32_t)n_whole;
     }
+    // ... and behind them the pieces of the remainder
+    a.fsplit_parts = parts;
+    a.fsplit_tile0 = (uint32_t)n_whole;
+    a.fsplit_first = (uint32_t)grid;
+    grid += (uint64_t)rest * parts;
     king_filter_kernel<<<dim3((uint32_t)grid), dim3(256), kFilterLdsBytes, stream>>>(a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;

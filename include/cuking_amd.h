@@ -216,7 +216,10 @@ cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
                                     int64_t value);
 /* Current value of "variant", "split_wgs", "band_rows", "xcd_swizzle",
  * "dyn_tail_tiles", "counts_mode", "reuse_prepared", "filter_quadrant_cap" or
- * "filter_cand_cap"; read-only counters
+ * "filter_cand_cap"; diagnostics of variant 7 that WAIT for the device:
+ * "filter_candidates" (pairs its bound has let through to the exact recount so
+ * far) and "filter_dense_quadrants" (128 x 128 quadrants it has handed to kernel
+ * 6 so far); read-only counters
  * "workspace_allocations", "host_syncs", "conversions_skipped". */
 cuking_status cuking_ctx_get_option(const cuking_ctx *ctx, const char *key,
                                     int64_t *value);

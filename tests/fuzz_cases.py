@@ -89,14 +89,15 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
         chunks = int(rng.integers(1, 9))
         streams = [int(rng.integers(1, 4)) for _ in range(world)]
         # filter variant: who computes a pair exactly (candidate list / dense quadrants)
-        qcap = int(rng.choice([1024, 1024, 0, 2]))
+        qcap = int(rng.choice([384, 384, 0, 2]))
         ccap = int(rng.choice([1 << 20, 1 << 20, 0, 5]))
+        smin = int(rng.choice([8, 1, 1]))      # remainder pieces of k even for short bitsets
         if case < first_case:
             continue
         tag = dict(fuzzer="run_general", seed=seed, case=case, n=n, m=m, split_factor=k,
                    shard=shard, thr=thr, kernel=kernel, variant=variant, counts_mode=mode,
                    xcd_swizzle=swizzle, band_rows=band, split_wgs=wgs, reuse_prepared=reuse,
-                   filter_quadrant_cap=qcap, filter_cand_cap=ccap)
+                   filter_quadrant_cap=qcap, filter_cand_cap=ccap, filter_split_min_steps=smin)
         osm = pyoracle.submatrix(n, k, shard)
         bits = pyoracle.bitset_from_genotypes(geno, osm)
         exp, _, _ = pyoracle.compute(osm, bits, thr, threads=8)
@@ -109,6 +110,7 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
         ctx.set_option("split_wgs", wgs)
         ctx.set_option("filter_quadrant_cap", qcap)
         ctx.set_option("filter_cand_cap", ccap)
+        ctx.set_option("filter_split_min_steps", smin)
         # (a new bitset may land on a recycled pointer: tell the library)
         ctx.set_option("reuse_prepared", reuse)
         ctx.invalidate()
@@ -138,8 +140,9 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
         if log and case % 25 == 0:
             log(f"run_general seed {seed} case {case} ok ({time.time() - t0:.0f}s)")
     ctx.set_option("reuse_prepared", 0)
-    ctx.set_option("filter_quadrant_cap", 1024)
+    ctx.set_option("filter_quadrant_cap", 384)
     ctx.set_option("filter_cand_cap", 1 << 20)
+    ctx.set_option("filter_split_min_steps", 8)
     return ran
 
 

@@ -1162,7 +1162,8 @@ def test_filter_variant_every_path_gives_the_oracle_records(ctx, oracle, missing
     exactly: candidate list + one wavefront per pair, or the four-product kernel
     over a dense quadrant.  Whatever the missingness (0.35: the bound lets most
     pairs through, whole quadrants go dense), however short the list and however
-    small the launch chunks, the records are the oracle's."""
+    small the launch chunks, with the remainder of the launch cut into pieces of k or not,
+    the records are the oracle's."""
     select(ctx, "tiled", 7)
     rng = np.random.default_rng(int(missing * 100) + 3)
     n, m = 1100, 2500                         # 5 x 5 tiles of 256, the last one ragged
@@ -1178,7 +1179,8 @@ def test_filter_variant_every_path_gives_the_oracle_records(ctx, oracle, missing
     idx = list(range(off.i_begin, off.i_end)) + list(range(off.j_begin, off.j_end))
     sub = np.ascontiguousarray(bits[idx])
     d_sub = ctx.upload_bitset(sub)
-    defaults = {"filter_quadrant_cap": 1024, "filter_cand_cap": 1 << 20, "max_launch_blocks": 0}
+    defaults = {"filter_quadrant_cap": 384, "filter_cand_cap": 1 << 20, "max_launch_blocks": 0,
+                "filter_split_min_steps": 8}
     try:
         for thr in (0.03, 0.0884, 0.2):
             exp, _, _ = oracle.compute(oracle.submatrix(n), bits, thr, threads=16)
@@ -1186,7 +1188,10 @@ def test_filter_variant_every_path_gives_the_oracle_records(ctx, oracle, missing
             assert len(exp) >= 30 * 29 // 2
             for opts in ({}, {"filter_quadrant_cap": 0}, {"filter_quadrant_cap": 3},
                          {"filter_cand_cap": 0}, {"filter_cand_cap": 7}, {"max_launch_blocks": 2},
-                         {"filter_cand_cap": 40, "max_launch_blocks": 3}):
+                         {"filter_cand_cap": 40, "max_launch_blocks": 3},
+                         # the launch's 15 tiles as 8 pieces of k each (remainder split)
+                         {"filter_split_min_steps": 1},
+                         {"filter_split_min_steps": 1, "max_launch_blocks": 7, "filter_quadrant_cap": 2}):
                 for k, v in {**defaults, **opts}.items():
                     ctx.set_option(k, v)
                 got = ctx.run(sm, bits.shape[1], d_bits, thr, max_results=1 << 20)
@@ -1224,3 +1229,27 @@ def test_filter_variant_tile_geometry_and_fallbacks(ctx, oracle):
         assert cuking_amd.sort_results(np.concatenate(parts)).tobytes() == exp.tobytes(), (thr, mode)
     ctx.set_option("counts_mode", -1)
     check_counts(ctx, oracle, sm, bits)
+
+
+@pytest.mark.parametrize("missing,thr", [(0.35, 0.05), (0.02, 0.004)])
+def test_filter_variant_gives_up_on_a_cohort_its_bound_cannot_thin_out(ctx, oracle, missing, thr):
+    """Heavy missingness, or a threshold inside the noise of unrelated pairs: nearly every
+    quadrant goes to the four-product kernel, and once most finished quadrants of a launch
+    have, the remaining tiles hand theirs over without computing the product at all
+    (1,200 quadrants on 256 CUs: the second round sees the first).  Same records."""
+    select(ctx, "tiled", 7, counts_mode=0)
+    rng = np.random.default_rng(5)
+    n, m = 6000, 500
+    geno = random_genotypes(rng, n, m, missing=missing)
+    geno[n - 1], geno[3000], geno[5900] = geno[7], geno[130], geno[5899]
+    bits = oracle.bitset_from_genotypes(geno)
+    exp, _, _ = oracle.compute(oracle.submatrix(n), bits, thr, threads=16)
+    d_bits = ctx.upload_bitset(bits)
+    sm = cuking_amd.Submatrix(n)
+    before = ctx.get_option("filter_dense_quadrants")
+    for _ in range(2):
+        got = ctx.run(sm, bits.shape[1], d_bits, thr, max_results=8 << 20)
+        assert got.tobytes() == exp.tobytes()
+    # (300 tiles = 1,176 quadrants with a pair i < j: most of them went dense, twice)
+    assert ctx.get_option("filter_dense_quadrants") - before > 2 * 600
+    ctx.set_option("counts_mode", -1)
