@@ -87,11 +87,23 @@ __global__ __launch_bounds__(256) void sample_stats_kernel(
     const uint32_t n = words_per_sample / 2;
     const uint64_t *het = bits + (uint64_t)src * words_per_sample;
     const uint64_t *hom = het + n;
-    for (uint32_t w = lane; w < n; w += 64) {
-      const uint64_t h = het[w], v = hom[w];
-      yc += __popcll(~h);      // homozygous and defined (missing has the het bit set)
-      mc += __popcll(h & v);   // missing
-      hc += __popcll(h & ~v);  // het
+    constexpr uint32_t kAhead = 4;  // words per lane and plane requested before any is counted
+    for (uint32_t w0 = 0; w0 < n; w0 += 64 * kAhead) {
+      uint64_t h[kAhead], v[kAhead];
+#pragma unroll
+      for (uint32_t k = 0; k < kAhead; ++k) {
+        const uint32_t w = w0 + 64 * k + lane;
+        const bool in = w < n;
+        h[k] = in ? het[w] : 0ull;
+        v[k] = in ? hom[w] : 0ull;
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < kAhead; ++k) {
+        const bool in = w0 + 64 * k + lane < n;  // beyond the plane: contributes nothing
+        yc += in ? __popcll(~h[k]) : 0;  // homozygous and defined (missing has the het bit set)
+        mc += __popcll(h[k] & v[k]);     // missing
+        hc += __popcll(h[k] & ~v[k]);    // het
+      }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
