@@ -96,6 +96,7 @@ def build_library(force: bool = False, save_temps: bool = False,
             sys.stderr.write((cwd / "build.log").read_text()[-8000:])
             raise subprocess.CalledProcessError(r.returncode, cmd)
     problems = check_mfma_loops(cwd / "king_mfma-hip-amdgcn-amd-amdhsa-gfx950.s")
+    problems += check_filter_loop(cwd / "king_filter-hip-amdgcn-amd-amdhsa-gfx950.s")
     if problems and not (tuning or os.environ.get("CUKING_EXTRA_HIPFLAGS")):
         LIB_PATH.unlink(missing_ok=True)
         raise RuntimeError("matrix-core kernel: the compiler put vector-memory waits or scratch "
@@ -104,6 +105,41 @@ def build_library(force: bool = False, save_temps: bool = False,
         print("warning (experiment build):", line, file=sys.stderr)
     LIB_FLAGS_PATH.write_text(wanted + "\n")
     return LIB_PATH
+
+
+def check_filter_loop(asm_path: Path, verbose: bool = False):
+    """The same check for king_filter_kernel (king_filter.hip): its k-loops hold LDS-DMA
+    requests and hand-counted waits (22 in flight at a hand-over; 30 with
+    -DCUKING_FILTER_FINE=1) and must hold no scratch access and no other vmcnt wait."""
+    import re
+    text = Path(asm_path).read_text()
+    m = re.search(r"\n_ZN6cuking12_GLOBAL__N_118king_filter_kernelE\w+:(.*?)\.Lfunc_end", text, re.S)
+    if not m:
+        return [f"no king_filter_kernel in {asm_path}"]
+    problems, seen = [], 0
+    for block in re.split(r"\n(?=\.LBB\d+_\d+:)", m.group(1)):
+        lines = block.split("\n")
+        head = lines[0].split(":")[0]
+        end = next((i for i, l in enumerate(lines)
+                    if re.search(r"s_cbranch_\w+ " + re.escape(head) + r"\b", l)), None)
+        if end is None:
+            continue
+        loop = lines[:end + 1]
+        mfma = sum("v_mfma" in l for l in loop)
+        if mfma < 16 or not any("global_load_lds" in l for l in loop):
+            continue
+        seen += 1
+        scratch = [l.strip() for l in loop if "scratch_" in l]
+        waits = [l.strip() for l in loop if re.search(r"s_waitcnt.*vmcnt\(\d+\)", l)]
+        foreign = [w for w in waits if not any(f"vmcnt({n})" in w for n in (22, 30))]
+        if verbose:
+            print(f"king_filter_kernel: loop {head} ({mfma} MFMAs): scratch {len(scratch)}, "
+                  f"vmcnt waits {waits}")
+        if scratch or foreign:
+            problems.append(f"king_filter_kernel, loop {head}: scratch {scratch[:2]}, waits {foreign}")
+    if seen == 0:
+        problems.append("king_filter_kernel: no LDS-DMA loop found (listing format changed?)")
+    return problems
 
 
 def check_mfma_loops(asm_path: Path, verbose: bool = False):

@@ -57,9 +57,21 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int kT = (int)kFilterTile;
-constexpr int kStages = 5;
-constexpr int kSliceU4 = kT;                     // one (side, k-half, slice): 256 samples
-constexpr int kStageU4 = 2 * 2 * 2 * kSliceU4;   // uint4 per stage (32 KiB)
+// LDS stages: 5 of 32 KiB (two units of 64 sites per k-half: a k-step of 256 sites), or
+// -DCUKING_FILTER_FINE=1: 10 of 16 KiB (one unit: 128 sites per k-step, a hand-over per
+// 32 MFMAs, 8 instead of 3 k-steps between a request and the hand-over that needs it).
+#ifndef CUKING_FILTER_FINE
+#define CUKING_FILTER_FINE 0
+#endif
+constexpr int kUnits = CUKING_FILTER_FINE ? 1 : 2;   // units per k-half and stage
+constexpr int kStages = CUKING_FILTER_FINE ? 10 : 5;
+constexpr int kSliceU4 = kT;                          // one (side, k-half, unit): 256 samples
+constexpr int kStageU4 = 2 * 2 * kUnits * kSliceU4;   // uint4 per stage
+constexpr int kStageReqs = 4 * kUnits;                // requests per wavefront and stage
+// requests that may be in flight at a hand-over: the stages after next, plus what the
+// k-step has issued before its last slice
+constexpr int kSyncVm = (kStages - 3) * kStageReqs + (kStageReqs - 2);
+static_assert(kSyncVm < 64, "vmcnt is a 6-bit counter");
 static_assert(kStages * kStageU4 * 16 == (int)kFilterLdsBytes, "LDS size");
 constexpr int vmcnt_imm(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
 constexpr uint32_t kNoPair = 0xFFFFFFFFu;
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   uint32_t lane16 = lane * 16;
   const uint32_t s_stride = a.geo.s_stride;
   // k-steps of 256 sites: all of them, or this piece's share
-  const uint32_t all_steps = a.geo.k_words / 8;
+  const uint32_t all_steps = a.geo.k_words / (4 * kUnits);
   // (wave-uniform, but divisions run in vector registers: pinned to SGPRs for the
   //  request addresses)
   const uint32_t k_first = __builtin_amdgcn_readfirstlane(
@@ -242,19 +254,19 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   const uint32_t dma_side = wave >> 1, dma_h = wave & 1;
   const uint32_t row_bytes = s_stride * 16;  // one unit of the layout
   const char *const g_wave = reinterpret_cast<const char *>(
-      (dma_side ? g_cols : g_rows) + ((uint64_t)4 * k_first + 2 * dma_h) * s_stride);
+      (dma_side ? g_cols : g_rows) + ((uint64_t)2 * kUnits * k_first + kUnits * dma_h) * s_stride);
   const uint32_t l_wave = (uint32_t)(uintptr_t)(lds_void_ptr)(
-      lds + ((dma_side * 2 + dma_h) * 2) * kSliceU4);
+      lds + ((dma_side * 2 + dma_h) * kUnits) * kSliceU4);
   struct Addr { const char *src; uint32_t dst; };  // of unit 0; unit 1: + row_bytes, + 4 KiB
   auto addr_of = [&](uint32_t step, uint32_t buf) {
     Addr pa;
     if (step >= num_steps) step = num_steps - 1;  // clamped repeats (see king_mfma.hip)
-    pa.src = g_wave + (uint64_t)step * 4 * row_bytes;
+    pa.src = g_wave + (uint64_t)step * 2 * kUnits * row_bytes;
     pa.dst = l_wave + buf * (kStageU4 * 16);
     asm volatile("" : "+s"(pa.src), "+s"(pa.dst));
     return pa;
   };
-  const uint32_t kstep_bytes = 4 * row_bytes;
+  const uint32_t kstep_bytes = 2 * kUnits * row_bytes;
   auto addr_next = [&](const Addr &cur, uint32_t step, uint32_t buf) {
     Addr pa;
     const uint32_t adv = step < num_steps ? kstep_bytes : 0u;
@@ -287,15 +299,15 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   for (int st = 0; st < kStages - 1; ++st) {
     const Addr p0 = addr_of(st, st);
     F_ISSUE4(p0, 0)
-    F_ISSUE4(p0, 1)
+    if (kUnits == 2) F_ISSUE4(p0, 1)
   }
   if (CUKING_FILTER_ABLATE != 1 && CUKING_FILTER_ABLATE != 2)
-    __builtin_amdgcn_s_waitcnt(vmcnt_imm(3 * 8));
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm((kStages - 2) * kStageReqs));
   __syncthreads();
 
   // This lane's operand words inside a stage (uint4 units).
-  uint32_t row_off = ((0 * 2 + g) * 2) * kSliceU4 + wy * 128 + lr;
-  uint32_t col_off = ((1 * 2 + g) * 2) * kSliceU4 + wx * 128 + lr;
+  uint32_t row_off = ((0 * 2 + g) * kUnits) * kSliceU4 + wy * 128 + lr;
+  uint32_t col_off = ((1 * 2 + g) * kUnits) * kSliceU4 + wx * 128 + lr;
   asm volatile("" : "+v"(row_off), "+v"(col_off), "+v"(lane16));
   v8i FA[2][4], FB[2][4];  // T fragments [slice parity][block]
   uint4 RAW[8];            // the words of one unit: rows 0-3, columns 4-7
@@ -363,7 +375,7 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
 #define F_SLICE_A(CUR, NXT, RBUF, RC, SYNC, PA, DC, OFF0, OFF1)                \
   {                                                                            \
     if ((SYNC) && CUKING_FILTER_ABLATE != 2) {                                 \
-      if (CUKING_FILTER_ABLATE != 1) __builtin_amdgcn_s_waitcnt(vmcnt_imm(2 * 8 + 6)); \
+      if (CUKING_FILTER_ABLATE != 1) __builtin_amdgcn_s_waitcnt(vmcnt_imm(kSyncVm)); \
       __syncthreads();                                                         \
     }                                                                          \
     const char *src_ = (PA).src + (DC) * row_bytes;                            \
@@ -404,6 +416,17 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   // in flight then may be stages s + 2, s + 3 and the six requests of stage s + 4
   // that the first three slices issued.
   Addr pa = addr_of(kStages - 1, kStages - 1);
+#if CUKING_FILTER_FINE
+#define F_KSTEP                                                                \
+  {                                                                            \
+    const uint32_t nbuf = buf == kStages - 1 ? 0 : buf + 1;                    \
+    F_SLICE_B(0, 1, pa, 0, 0, 1024)                                            \
+    F_SLICE_A(1, 0, nbuf, 0, true, pa, 0, 2048, 3072)                          \
+    pa = addr_next(pa, step + kStages, buf);                                   \
+    buf = nbuf;                                                                \
+    ++step;                                                                    \
+  }
+#else
 #define F_KSTEP                                                                \
   {                                                                            \
     const uint32_t nbuf = buf == kStages - 1 ? 0 : buf + 1;                    \
@@ -415,12 +438,23 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
     buf = nbuf;                                                                \
     ++step;                                                                    \
   }
+#endif
   uint32_t step = 0;
+#if CUKING_FILTER_FINE
+  while (step + 3 < num_steps) {
+    F_KSTEP
+    F_KSTEP
+    F_KSTEP
+    F_KSTEP
+  }
+  while (step < num_steps) F_KSTEP
+#else
   while (step + 1 < num_steps) {
     F_KSTEP
     F_KSTEP
   }
   if (step < num_steps) F_KSTEP
+#endif
 #undef F_KSTEP
 #undef F_SLICE_A
 #undef F_SLICE_B
@@ -743,7 +777,7 @@ hipError_t launch_filter(const TiledArgs &args, uint64_t num_tiles, hipStream_t 
         // (pieces of at least 8 k-steps -- on entry args.fsplit_first, a test hook --:
         //  the pipeline's fill and the slab are per piece)
         const uint32_t min_steps = args.fsplit_first != 0 ? args.fsplit_first : 8;
-        while (parts > 1 && args.geo.k_words / 8 / parts < min_steps) --parts;
+        while (parts > 1 && args.geo.k_words / 8 / parts < min_steps) --parts;  // (k-steps of 256 sites)
       }
       if (parts < 2) rest = parts = 0;
     }
