@@ -209,14 +209,15 @@ cuking_status cuking_ctx_set_kernel(cuking_ctx *ctx, cuking_kernel kernel);
  * for every pair; -1 = automatic: lean when kin_threshold > c / sqrt(sites), c = 2.05 (1.6 for the VALU variants),
  * i.e. when few pairs are expected to pass).  Test hooks of variant 7:
  * "filter_quadrant_cap" (candidates per 128 x 128 quadrant beyond which the
- * quadrant goes to kernel 6, default 1024) and "filter_cand_cap" (entries of the
- * candidate list per launch, default 2^20).  Results do not depend on any of
- * them. */
+ * quadrant goes to kernel 6, default 384), "filter_cand_cap" (entries of the
+ * candidate list per launch, default 2^20) and "filter_split_min_steps" (k-steps
+ * of 256 sites a piece of a short launch's remainder must have, default 8).
+ * Results do not depend on any of them. */
 cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
                                     int64_t value);
 /* Current value of "variant", "split_wgs", "band_rows", "xcd_swizzle",
- * "dyn_tail_tiles", "counts_mode", "reuse_prepared", "filter_quadrant_cap" or
- * "filter_cand_cap"; diagnostics of variant 7 that WAIT for the device:
+ * "dyn_tail_tiles", "counts_mode", "reuse_prepared", "filter_quadrant_cap",
+ * "filter_cand_cap" or "filter_split_min_steps"; diagnostics of variant 7 that WAIT for the device:
  * "filter_candidates" (pairs its bound has let through to the exact recount so
  * far) and "filter_dense_quadrants" (128 x 128 quadrants it has handed to kernel
  * 6 so far); read-only counters
