@@ -680,7 +680,10 @@ __global__ __launch_bounds__(256) void king_refine_kernel(const TiledArgs a) {
     const uint64_t *het_j_w = a.bits + (uint64_t)off_j * a.words_per_sample;
     const uint64_t *alt_j_w = het_j_w + n;
     uint32_t s_het_i = 0, s_het_j = 0, s_both = 0, s_opp = 0, s_conc = 0, s_shared = 0;
-    constexpr uint32_t kAhead = 4;  // words per lane and plane requested before any is counted
+    // words per lane and plane requested before any is counted: the planes of an arbitrary
+    // pair are cold, a trip is one memory latency (100k sites: 4 trips; 21 us for the 770
+    // candidates of configs[1] with 4 words in flight)
+    constexpr uint32_t kAhead = 8;
     for (uint32_t w0 = 0; w0 < n; w0 += 64 * kAhead) {
       uint64_t hi[kAhead], ai[kAhead], hj[kAhead], aj[kAhead];
 #pragma unroll
