@@ -325,6 +325,10 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   if (listed) {
     list_count = *a.tile_list_count;
     if (list_count > a.tile_list_cap) list_count = a.tile_list_cap;
+    // Workgroups are dealt round-robin to the 8 XCDs: give the ones that share an
+    // XCD (and its L2) CONSECUTIVE entries of every round -- the list is in tile
+    // order more or less, neighbours share row / column strips.
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
     if (bid >= list_count) return;  // uniform
   }
   bid = __builtin_amdgcn_readfirstlane(bid);
