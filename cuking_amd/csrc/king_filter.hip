@@ -22,11 +22,13 @@
 // the usual thresholds (>= 0.04) next to nothing but real records gets through.
 //
 // Pipeline per launch chunk (<= kFilterChunkTiles tiles of 256 x 256 pairs):
-//   1. king_filter_kernel: q for every pair on the matrix cores (T is the
-//      nibble layout's bits 2-3, +-2.0 in fp4: one v_and per fragment dword, the
-//      accumulators carry 4 q), the test above per pair; candidates are appended
-//      to a list, or, when a 128 x 128 quadrant has more than quadrant_cap of
-//      them (or the list is full), the quadrant is put on the dense list.
+//   1. king_filter_kernel: q for every pair on the matrix cores (T from the
+//      two-bit T2 layout, king_common.h: +-2.0 in fp4 after one v_and -- or a
+//      shift and a v_and -- per fragment dword; the accumulators carry 4 q), the
+//      test above per pair; candidates are appended to a list, or, when a 128 x
+//      128 quadrant has more than quadrant_cap of them (or the list is full), the
+//      quadrant is put on the dense list.  Once most finished quadrants of a
+//      launch have gone dense the remaining tiles hand theirs over unexamined.
 //   2. king_refine_kernel: one wavefront per candidate, the reference's own six
 //      sums straight from the bitset (king_kernels.hip stream kernel), exact
 //      kinship, record.
@@ -36,9 +38,10 @@
 // decides WHO computes a pair exactly.
 //
 // Workgroup = 256 x 256 pairs, 4 wavefronts of 128 x 128 = 4 x 4 MFMA blocks (256
-// accumulator registers), k-step = 128 sites = 2 slices of 64, 5 LDS stages of
-// 32 KiB by LDS-DMA.  Per slice and wavefront: 16 MFMAs, 8 ds_read_b128, 32
-// v_and, 4 requests of 1 KiB.
+// accumulator registers), k-step = 256 sites = 4 slices of 64, 5 LDS stages of
+// 32 KiB by LDS-DMA.  Per k-step and wavefront: 64 MFMAs, 16 ds_read_b128, 192
+// VALU (128 v_and + 64 v_lshl), 8 requests of 1 KiB.  DESIGN.md 4.0 has the
+// measurements; profiles/r03_ablation.txt and r03_filter_curve.txt the raw numbers.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -164,7 +167,7 @@ __device__ __forceinline__ uint4 shl2(const uint4 w) {
                : "memory", "m0")
 
 __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) {
-  extern __shared__ uint4 lds[];  // [kStages][side][k-half][slice][256]
+  extern __shared__ uint4 lds[];  // [kStages][side][k-half][unit][256]
 
   uint32_t bid = blockIdx.x;
   // Remainder of a short launch (king_common.h, fsplit_*): piece `part` of the k
@@ -410,11 +413,11 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
     F_BUILD_B(0, k)
   }
   uint32_t buf = 0;  // buffer of the k-step being multiplied
-  // k-step s requests stage s + 4 into the buffer stage s - 1 left: every
+  // k-step s requests stage s + kStages - 1 into the buffer stage s - 1 left: every
   // wavefront finished reading it before the hand-over of k-step s - 1.  The
   // hand-over of k-step s (stage s + 1 must have landed) comes in its last slice:
-  // in flight then may be stages s + 2, s + 3 and the six requests of stage s + 4
-  // that the first three slices issued.
+  // in flight then may be the stages after s + 1 and the requests of the newest one
+  // that the slices before the last have issued (kSyncVm: 2 x 8 + 6 = 22).
   Addr pa = addr_of(kStages - 1, kStages - 1);
 #if CUKING_FILTER_FINE
 #define F_KSTEP                                                                \
