@@ -124,8 +124,11 @@ wps = bench["roofline"].get("hbm", {}).get("algorithmic_bytes_per_pair", 0) // 1
 for name, d in durations.items():
     if name.startswith("prepare_"):
         read = cfg["samples"] * wps * 8
-        # (nibble layout: 4 bits per site + the het-only copy; word layout 2 x)
-        write = read * 9 // 4 if "nibbles" in name else read * (2 if "planes" in name else 1)
+        # (bits per site and sample: the reference layout 2; nibble layout 4 + the het-only
+        #  copy 1, and with <true> the two-bit T2 layout as well; word layout 4; quad layout 2)
+        write = (read * 7 // 2 if "nibbles_kernel<true>" in name else
+                 read * 5 // 2 if "nibbles" in name else
+                 read * (2 if "planes" in name else 1))
         gbps = (read + write) / (d["median_ms"] * 1e-3) / 1e9
         table[f"{key}:{name}"] = {
             "round": rnd, "kernel": name, "bound": "hbm", "median_ms": d["median_ms"],
