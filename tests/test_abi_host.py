@@ -282,3 +282,37 @@ def test_matrix_core_loops_hold_no_foreign_waits():
         assert build.check_mfma_loops(broken) != []
     finally:
         broken.unlink()
+
+
+def test_filter_kernel_loop_holds_no_foreign_waits_and_no_scratch():
+    """The same for king_filter_kernel (the default pair kernel): its k-loop holds the
+    hand-counted `vmcnt(22)` hand-overs only, and no scratch access."""
+    from cuking_amd import build
+    asm = build.PKG / "build_tmp" / "king_filter-hip-amdgcn-amd-amdhsa-gfx950.s"
+    if not asm.exists() or asm.stat().st_mtime < (build.CSRC / "king_filter.hip").stat().st_mtime:
+        build.build_library(force=True)
+    assert build.check_filter_loop(asm) == []
+    text = asm.read_text()
+    bad = text.replace("s_waitcnt vmcnt(22)", "s_waitcnt vmcnt(0)\n\ts_waitcnt vmcnt(22)")
+    assert bad != text
+    broken = asm.with_suffix(".broken.s")
+    broken.write_text(bad)
+    try:
+        assert build.check_filter_loop(broken) != []
+    finally:
+        broken.unlink()
+
+
+def test_default_variant_and_its_tile_geometry_without_a_context():
+    """Host-side facts a multi-GPU driver relies on before it has a device: eight
+    compiled shapes, the default one is the filter variant with 256-sample tiles, and
+    the tile enumeration of a block follows from that alone."""
+    lib = _lib.load()
+    assert lib.cuking_num_variants() == 8
+    names = [lib.cuking_variant_name(v).decode() for v in range(8)]
+    assert names[7] == "t256_mfma_fp4_filter" and names[6] == "t128_mfma_fp4_n4"
+    assert names[5] == "t128_mfma_fp4" and lib.cuking_variant_name(8) == b""
+    if "CUKING_AMD_VARIANT" not in __import__("os").environ:
+        assert lib.cuking_tile_samples(None) == 256
+        sm = cuking_amd.Submatrix(100_000)
+        assert lib.cuking_num_tiles(None, C.byref(sm.c)) == 391 * 392 // 2
