@@ -240,6 +240,10 @@ PlaneGeometry make_geometry(const cuking_submatrix &sm,
 uint32_t band_rows_for(uint32_t pinned, const PlaneGeometry &g, const TiledVariant &v) {
   if (pinned != 0) return pinned;
   if (v.layout == kLayoutWord) return 17;
+  // 256-sample tiles (filter variant): 8 rows x 4 columns per XCD patch at every size
+  // (configs[2]: 146.8 ms against 147.4 with 5 rows and 147.2 with 17; configs[1]: 1.78
+  // against 1.81 with 17; profiles/r03_ablation.txt)
+  if (v.tile == kFilterTile) return 8;
   return g.rows_padded / v.tile >= 128 ? 5 : 17;
 }
 
