@@ -215,11 +215,21 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   // worst case costs the exact kernel's time plus the first round of this one
   // (filter_ctrl[1] dense quadrants, [3] quadrants finished; both per launch).
   if (!split) {
-    const uint32_t dense_so_far = __hip_atomic_load(a.filter_ctrl + 1, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t finished = __hip_atomic_load(a.filter_ctrl + 3, __ATOMIC_RELAXED,
-                                                __HIP_MEMORY_SCOPE_AGENT);
-    if (finished >= 512 && 2 * dense_so_far > finished) {  // uniform
+    // ONE decision per workgroup (the counters move while the wavefronts read them,
+    // and a wavefront that left alone would take its quarter of every stage's
+    // requests with it): thread 0 reads, the stage memory carries the verdict.
+    uint32_t *verdict = reinterpret_cast<uint32_t *>(lds);
+    if (threadIdx.x == 0) {
+      const uint32_t dense_so_far = __hip_atomic_load(a.filter_ctrl + 1, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t finished = __hip_atomic_load(a.filter_ctrl + 3, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT);
+      *verdict = (finished >= 512 && 2 * dense_so_far > finished) ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool give_up = *verdict != 0;
+    __syncthreads();  // the word is stage memory from here on
+    if (give_up) {  // uniform across the workgroup
       if (lane == 0 && !(a.tiles.diag && 2 * tc + wx < 2 * tr + wy)) {
         const uint32_t slot = __hip_atomic_fetch_add(a.filter_ctrl + 1, 1u, __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_AGENT);
