@@ -214,7 +214,10 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   // remaining tiles skip the product and hand their quadrants over directly, so the
   // worst case costs the exact kernel's time plus the first round of this one
   // (filter_ctrl[1] dense quadrants, [3] quadrants finished; both per launch).
-  if (!split) {
+#ifndef CUKING_FILTER_GIVE_UP
+#define CUKING_FILTER_GIVE_UP 1  // (A/B: 0 = tiles never give up)
+#endif
+  if (CUKING_FILTER_GIVE_UP && !split) {
     // ONE decision per workgroup (the counters move while the wavefronts read them,
     // and a wavefront that left alone would take its quarter of every stage's
     // requests with it): thread 0 reads, the stage memory carries the verdict.
