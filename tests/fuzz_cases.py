@@ -68,6 +68,8 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
         m = int(rng.integers(1, 2500))
         if rng.random() < 0.15:   # enough tiles for the XCD-aware order (launches of >= 64 tiles)
             n = int(rng.integers(1400, 2300))
+        elif rng.random() < 0.03:  # > 512 quadrants of the filter variant: tiles may give up
+            n, m = int(rng.integers(4700, 6200)), int(rng.integers(100, 600))
         k = int(rng.integers(1, 4))
         shard = int(rng.integers(0, k * (k + 1) // 2))
         thr = float(rng.choice([-1e30, -0.2, 0.0, 0.03, 0.0884, 0.3]))
