@@ -7,7 +7,8 @@ every rate: kernel time per pass of both variants (HIP events around the whole c
 filter + refine + dense-quadrant kernels), candidates, dense quadrants -- and the records
 of the two variants compared byte for byte.
 
-usage: python tools/missing_curve.py [samples] [sites] [threshold ...] -> gpurun_out/missing_curve.txt
+usage: [MISSING_KS=0,3] python tools/missing_curve.py [samples] [sites] [threshold ...]
+       -> gpurun_out/missing_curve.txt
 """
 import sys
 import os
@@ -98,7 +99,8 @@ def main():
 
     say(f"# {n} samples x {m} sites, synthetic cohort (1 % missing) + extra missing calls of density 2^-k;")
     say("# lean form forced; kernel_ms = HIP events around the whole call; records of variants 7 and 6 compared")
-    for k in (0, 6, 5, 4, 3, 2):
+    ks = [int(x) for x in os.environ.get("MISSING_KS", "0,6,5,4,3,2").split(",")]
+    for k in ks:
         bits = extra_missing(base, k, gen)
         half = wps // 2
         # measured missing rate over the stored sites (padding sites of the last word included)
