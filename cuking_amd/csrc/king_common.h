@@ -263,7 +263,11 @@ constexpr uint32_t kFilterLdsBytes = 5 * 2 * 2 * 2 * 256 * 16;  // 5 x 32 KiB
 static_assert(kFilterLdsBytes <= 160 * 1024, "LDS of one CU");
 // Per launch chunk: at most this many 256-tiles (bounds the dense-quadrant list).
 constexpr uint32_t kFilterChunkTiles = 1u << 17;
-constexpr uint32_t kFilterCandCap = 1u << 20;      // candidate pairs per chunk
+// Candidate pairs per chunk: 64 per quadrant of a full chunk.  (2^20 until the missing-rate
+// curve, profiles/r03_missing_curve.txt: at configs[2] with 7 % missing the bound lets 4 x 10^6
+// pairs through -- 14 ms of recounts -- but the list was full after the first million and
+// 230,000 quadrants went to the exact kernel instead, 512 ms for a 160 ms pass.)
+constexpr uint32_t kFilterCandCap = 1u << 25;
 // Candidates per 128 x 128 quadrant beyond which the quadrant goes to the exact
 // kernel: one wavefront per candidate costs 3.4 ns of chip time at 100k sites
 // (1.65 M candidates in 5.6 ms), the four-product kernel 1.85 us per quadrant --

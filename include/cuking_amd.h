@@ -210,7 +210,7 @@ cuking_status cuking_ctx_set_kernel(cuking_ctx *ctx, cuking_kernel kernel);
  * i.e. when few pairs are expected to pass).  Test hooks of variant 7:
  * "filter_quadrant_cap" (candidates per 128 x 128 quadrant beyond which the
  * quadrant goes to kernel 6, default 384), "filter_cand_cap" (entries of the
- * candidate list per launch, default 2^20) and "filter_split_min_steps" (k-steps
+ * candidate list per launch chunk, default 2^25) and "filter_split_min_steps" (k-steps
  * of 256 sites a piece of a short launch's remainder must have, default 8).
  * Results do not depend on any of them. */
 cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,

@@ -1179,7 +1179,7 @@ def test_filter_variant_every_path_gives_the_oracle_records(ctx, oracle, missing
     idx = list(range(off.i_begin, off.i_end)) + list(range(off.j_begin, off.j_end))
     sub = np.ascontiguousarray(bits[idx])
     d_sub = ctx.upload_bitset(sub)
-    defaults = {"filter_quadrant_cap": 384, "filter_cand_cap": 1 << 20, "max_launch_blocks": 0,
+    defaults = {"filter_quadrant_cap": 384, "filter_cand_cap": 1 << 25, "max_launch_blocks": 0,
                 "filter_split_min_steps": 8}
     try:
         for thr in (0.03, 0.0884, 0.2):

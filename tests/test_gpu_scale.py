@@ -116,7 +116,7 @@ def test_c2_100k_x_100k_whole_triangle(ctx, oracle):
     ctx.set_option("variant", MFMA)
     # ... the filter variant with every quadrant that has a candidate handed to the
     # four-product kernel, and with a candidate list of 100 entries
-    for key, value, back in (("filter_quadrant_cap", 0, 384), ("filter_cand_cap", 100, 1 << 20)):
+    for key, value, back in (("filter_quadrant_cap", 0, 384), ("filter_cand_cap", 100, 1 << 25)):
         ctx.set_option(key, value)
         assert ctx.run(sm, wps, bits, thr, max_results=4 << 20).tobytes() == res.tobytes(), key
         ctx.set_option(key, back)

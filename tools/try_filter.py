@@ -40,7 +40,7 @@ def check(ctx, n, m, seed, thr, split=1, shard=0, label="", **opts):
           f"vs variant 6 {'OK' if ok6 else 'MISMATCH'}, vs oracle {'OK' if oko else 'MISMATCH'}",
           flush=True)
     for k in opts:
-        ctx.set_option(k, {"filter_quadrant_cap": 384, "filter_cand_cap": 1 << 20,
+        ctx.set_option(k, {"filter_quadrant_cap": 384, "filter_cand_cap": 1 << 25,
                            "counts_mode": -1, "max_launch_blocks": 0}[k])
     return ok6 and oko
 
