@@ -16,6 +16,7 @@
 #include <chrono>
 #include <future>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <iomanip>
 #include <iostream>
@@ -796,6 +797,17 @@ int main(int argc, char **argv) {
   if (flags.help) {
     std::cout << cuking_host::Usage();
     return 0;
+  }
+  if (flags.variant >= 0) {
+    // The library reads its default variant from the environment wherever it needs one --
+    // contexts of every rank, and the tile geometry the schedules are cut from before any
+    // context exists: one setting for all of them.
+    if (flags.variant >= cuking_num_variants()) {
+      std::cerr << "ERROR: Illegal value '" << flags.variant << "' specified for flag 'variant'"
+                << std::endl;
+      return 1;
+    }
+    setenv("CUKING_AMD_VARIANT", std::to_string(flags.variant).c_str(), 1);
   }
   const Status status = Run(flags);
   if (!status.ok()) {  // cuking.cu:889-892

@@ -50,6 +50,10 @@ std::string Usage() {
          "  --requester_pays_project=P  accepted for compatibility, unused\n"
          "  --device=D             GPU index (default 0)\n"
          "  --kernel=tiled|stream  device kernel (default tiled)\n"
+         "  --variant=N            tiled kernel variant (default: the library's, 7 = one-product "
+         "filter + exact recount; 6 = four products for every pair: the choice when more than "
+         "~10 % of the calls are missing or the threshold sits inside the noise of unrelated "
+         "pairs; same records either way)\n"
          "  --pack=host|device|auto  where triples are packed (default auto: device when at "
          "most 32 reader threads feed the GPU)\n"
          "  --num_gpus=N           share the shard among N GPUs of this node over "
@@ -139,6 +143,10 @@ std::string ParseFlags(int argc, char **argv, Flags *flags) {
       if (!need_value() || (value != "tiled" && value != "stream"))
         return "Illegal value '" + value + "' specified for flag 'kernel'";
       flags->kernel = value;
+    } else if (name == "variant") {
+      if (!need_value() || !ParseUnsigned(value, 63, &u))
+        return "Illegal value '" + value + "' specified for flag 'variant'";
+      flags->variant = (int)u;
     } else if (name == "dump_bitset") {
       if (!need_value()) return "Missing value for --dump_bitset";
       flags->dump_bitset = value;

@@ -25,6 +25,7 @@ struct Flags {
   // Additions (no reference counterpart).
   int device = 0;                       // HIP device index
   std::string kernel = "tiled";         // tiled | stream
+  int variant = -1;                     // tiled kernel variant (library option "variant"); -1: the default
   std::string pack = "auto";            // host | device | auto (device when the
                                         // reader threads per GPU are few, cuking_main.cc)
   std::string dump_bitset;              // diagnostic: write the packed host

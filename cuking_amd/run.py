@@ -45,6 +45,10 @@ def parse_args(argv=None):
     flag("split-factor", type=int, default=1)
     flag("shard-index", type=int, default=0)
     flag("chunks", type=int, default=8)
+    flag("variant", type=int, default=-1,
+         help="tiled kernel variant (default: the library's, 7 = one-product filter + exact "
+              "recount; 6 = four products for every pair, the choice when more than ~10 %% of "
+              "the calls are missing; same records either way)")
     flag("synthetic", default="",
          help="N,M[,seed]: instead of reading --input-uri, generate the synthetic cohort of "
               "cuking_amd.synth on the GPU (BASELINE configs without their 10^9..10^11-row "
@@ -179,6 +183,8 @@ def main(argv=None) -> int:
         sm = cuking_amd.Submatrix(len(sample_ids), args.split_factor, args.shard_index)
         wps = cuking_amd.words_per_sample(num_sites)
         ctx = cuking_amd.KingContext(local_rank)
+        if args.variant >= 0:   # (every geometry call below goes through this context)
+            ctx.set_option("variant", args.variant)
         stored = sm.NumSamples()
         bits = torch.zeros((max(stored, 1), wps), dtype=torch.int64, device=dev)
         # Rank 0 reads and packs; its outcome is agreed on before anybody

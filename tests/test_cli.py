@@ -174,6 +174,33 @@ def test_multi_gpu_schedule_matches_python_driver(tmp_path, n, k, shard, world, 
                 assert tuple(step["rows"]) == rect[0] and rect[1] == (c0, c1)
 
 
+def test_variant_flag_sets_the_geometry_of_the_schedules(tmp_path):
+    """`--variant=N` (the four-product kernel for callsets the filter's bound cannot thin
+    out) reaches the library's default before anything is cut: the
+    schedule of a --num_gpus run is in that variant's tiles; out of range is an error."""
+    d = tmp_path / "in"
+    d.mkdir()
+    (d / "metadata.json").write_text(json.dumps(
+        {"num_sites": 64, "samples": [f"s{i}" for i in range(1000)]}))
+    lib = cuking_amd._lib.load()
+    tiles = {}
+    for args in ((), ("--variant=7",), ("--variant=6",), ("--variant", "0")):
+        p = run_cli("--input_uri", d, "--output_uri", tmp_path / "o", "--print_schedule",
+                    "--num_gpus=2", *args, check=True)
+        got = json.loads(p.stdout.strip().splitlines()[-1])
+        tiles[" ".join(args)] = (got["tile"], got["num_tiles"])
+    assert tiles[""] == tiles["--variant=7"]            # the default is the filter variant
+    assert tiles["--variant=7"][0] == 256 and tiles["--variant=6"][0] == 128
+    assert tiles["--variant=6"][1] > tiles["--variant=7"][1]
+    assert tiles["--variant 0"][0] in (64, 128)
+    n_variants = lib.cuking_num_variants()
+    for bad in (str(n_variants), "-1", "x"):
+        p = run_cli("--input_uri", d, "--output_uri", tmp_path / "o", "--print_schedule",
+                    f"--variant={bad}")
+        assert p.returncode == 1 and "flag 'variant'" in p.stderr, bad
+    assert "--variant=N" in run_cli("--help", check=True).stdout
+
+
 def test_weighted_tile_ranges_and_calibration_plan(tmp_path):
     """`--rank_weights` / calibration of the simple schedule (host/schedule.h)
     against cuking_amd.dist.weighted_tile_partition, and the new flags' errors."""
