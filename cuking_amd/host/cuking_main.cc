@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <functional>
 #include <future>
 #include <cstdio>
 #include <cstdlib>
@@ -156,6 +157,30 @@ struct DeviceBuffers {
   }
 };
 
+uint64_t NowMicros() {
+  return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(
+             std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// --decode=stream: hands every decoded batch to the pack of the run (host or device),
+// counts the triples and the time spent packing.
+struct BatchSink : cuking_host::TripleSink {
+  using PackFn = std::function<std::string(const int64_t *, const int64_t *, const int32_t *,
+                                           size_t)>;
+  PackFn pack_batch;
+  size_t triples = 0;
+  uint64_t pack_time_us = 0;
+  explicit BatchSink(PackFn p) : pack_batch(std::move(p)) {}
+  std::string Consume(const int64_t *row, const int64_t *col, const int32_t *alt,
+                      size_t count) override {
+    const uint64_t t0 = NowMicros();
+    std::string err = pack_batch(row, col, alt, count);
+    pack_time_us += NowMicros() - t0;
+    triples += count;
+    return err;
+  }
+};
+
 // --pack=device: one per reader thread.  A decoded table goes to the GPU in
 // pieces of kChunkTriples through a ring of kSlots page-locked buffers: each
 // piece is filtered to the shard and narrowed to 8 bytes per genotype on the
@@ -199,8 +224,8 @@ class DevicePacker {
 
   // Returns "" or "<CODE>\n<message>".
   std::string Pack(const cuking_submatrix &sm, uint32_t words_per_sample,
-                   uint64_t *d_bits, const cuking_host::Triples &t,
-                   uint32_t *d_status) {
+                   uint64_t *d_bits, const int64_t *row_idx, const int64_t *col_idx,
+                   const int32_t *n_alt_alleles, size_t n, uint32_t *d_status) {
     auto abi_error = [](cuking_status st) {
       const char *code = st == CUKING_ERR_FAILED_PRECONDITION ? "FAILED_PRECONDITION"
                          : st == CUKING_ERR_INVALID_ARGUMENT  ? "INVALID_ARGUMENT"
@@ -211,7 +236,6 @@ class DevicePacker {
       return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(
                  std::chrono::steady_clock::now().time_since_epoch()).count();
     };
-    const size_t n = t.row_idx.size();
     for (size_t done = 0; done < n; done += kChunkTriples) {
       const size_t m = std::min(kChunkTriples, n - done);
       const int b = next_;
@@ -228,8 +252,8 @@ class DevicePacker {
       uint32_t *h_sa = h_site + m;
       size_t kept = 0;
       cuking_status st = cuking_narrow_triples(
-          &sm, words_per_sample, t.row_idx.data() + done, t.col_idx.data() + done,
-          t.n_alt_alleles.data() + done, m, h_site, h_sa, &kept);
+          &sm, words_per_sample, row_idx + done, col_idx + done, n_alt_alleles + done, m,
+          h_site, h_sa, &kept);
       if (st != CUKING_OK) return abi_error(st);
       t0 = now();
       if (stats) stats->narrow_us += t0 - t1;
@@ -542,32 +566,61 @@ Status Run(const Flags &flags) {
   const std::string pack_error = cuking_host::ParallelFor(
       flags.num_reader_threads, 0, tasks.size(), [&](size_t task) -> std::string {
         const size_t f = tasks[task].first;
-        cuking_host::Triples t;
-        const uint64_t t_begin = now_us();
-        std::string err = cuking_host::ReadTriples(input_files[f].first, tasks[task].second, &t);
-        if (!err.empty()) return "FAILED_PRECONDITION\n" + err;
-        const size_t n = t.row_idx.size();
-        const uint64_t t_decoded = now_us();
-        decode_us += t_decoded - t_begin;
-        if (!device_pack) {
-          if (cuking_pack_host(&sm, words_per_sample, host_bits, t.row_idx.data(),
-                               t.col_idx.data(), t.n_alt_alleles.data(), n) != CUKING_OK)
-            return std::string("FAILED_PRECONDITION\n") + cuking_last_error() + " in " +
-                   input_files[f].first;
-        } else if (n > 0) {
-          // One packer (stream + staging ring) per reader thread.
+        const std::string &path = input_files[f].first;
+        // One batch of triples into the bitset: the host's, or through this reader
+        // thread's packer (stream + staging ring) the device's.
+        auto pack = [&](const int64_t *row, const int64_t *col, const int32_t *alt,
+                        size_t count) -> std::string {
+          if (!device_pack) {
+            if (cuking_pack_host(&sm, words_per_sample, host_bits, row, col, alt, count) !=
+                CUKING_OK)
+              return std::string("FAILED_PRECONDITION\n") + cuking_last_error() + " in " + path;
+            return "";
+          }
+          if (count == 0) return "";
           thread_local DevicePacker *packer = nullptr;
           if (packer == nullptr) {
             setup_done.wait();
             if (!setup_error.empty()) return "INTERNAL\n" + setup_error;
             packer = packers[next_packer.fetch_add(1) % packers.size()].get();
           }
-          const std::string msg =
-              packer->Pack(sm, words_per_sample, static_cast<uint64_t *>(buf.d_bits), t,
-                           d_pack_status);
-          if (!msg.empty()) return msg + " in " + input_files[f].first;
+          const std::string msg = packer->Pack(sm, words_per_sample,
+                                               static_cast<uint64_t *>(buf.d_bits), row, col,
+                                               alt, count, d_pack_status);
+          return msg.empty() ? msg : msg + " in " + path;
+        };
+        const uint64_t t_begin = now_us();
+        size_t n = 0;
+        if (flags.decode == "stream" || (flags.decode == "auto" && !device_pack)) {
+          // Batches packed as they are decoded: small enough to stay in the cache for
+          // the host pack, one staging slot's worth for the device pack.
+          BatchSink sink(pack);
+          thread_local cuking_host::TripleScratch scratch;
+          const size_t batch = flags.decode_batch != 0 ? flags.decode_batch
+                               : device_pack         ? DevicePacker::kChunkTriples
+                                                     : size_t(32) << 10;
+          std::string err = cuking_host::StreamTriples(path, tasks[task].second, batch, &scratch,
+                                                       &sink);
+          if (!err.empty())
+            return err.rfind("FAILED_PRECONDITION\n", 0) == 0 || err.rfind("INTERNAL\n", 0) == 0 ||
+                           err.rfind("INVALID_ARGUMENT\n", 0) == 0
+                       ? err
+                       : "FAILED_PRECONDITION\n" + err;
+          n = sink.triples;
+          const uint64_t total = now_us() - t_begin;
+          pack_us += sink.pack_time_us;
+          decode_us += total > sink.pack_time_us ? total - sink.pack_time_us : 0;
+        } else {
+          cuking_host::Triples t;
+          std::string err = cuking_host::ReadTriples(path, tasks[task].second, &t);
+          if (!err.empty()) return "FAILED_PRECONDITION\n" + err;
+          n = t.row_idx.size();
+          const uint64_t t_decoded = now_us();
+          decode_us += t_decoded - t_begin;
+          err = pack(t.row_idx.data(), t.col_idx.data(), t.n_alt_alleles.data(), n);
+          if (!err.empty()) return err;
+          pack_us += now_us() - t_decoded;
         }
-        pack_us += now_us() - t_decoded;
         num_triples += n;
         if ((++num_processed & 1023) == 0) std::cout << "." << std::flush;  // :705-708
         return "";

@@ -56,6 +56,9 @@ std::string Usage() {
          "pairs; same records either way)\n"
          "  --pack=host|device|auto  where triples are packed (default auto: device when at "
          "most 32 reader threads feed the GPU)\n"
+         "  --decode=table|stream|auto  table: decode a whole table (or row group), then pack "
+         "it; stream: pack batches of triples as they are decoded (no column-sized buffers); "
+         "default auto: stream for the host pack, table for the device pack\n"
          "  --num_gpus=N           share the shard among N GPUs of this node over "
          "RCCL (default 0: one GPU, no RCCL)\n"
          "  --multi_gpu_mode=auto|staged|simple  broadcast overlapped with compute "
@@ -191,6 +194,14 @@ std::string ParseFlags(int argc, char **argv, Flags *flags) {
       if (!need_value() || (value != "host" && value != "device" && value != "auto"))
         return "Illegal value '" + value + "' specified for flag 'pack'";
       flags->pack = value;
+    } else if (name == "decode") {
+      if (!need_value() || (value != "table" && value != "stream" && value != "auto"))
+        return "Illegal value '" + value + "' specified for flag 'decode'";
+      flags->decode = value;
+    } else if (name == "decode_batch") {
+      if (!need_value() || !ParseUnsigned(value, 1u << 24, &u))
+        return "Illegal value '" + value + "' specified for flag 'decode_batch'";
+      flags->decode_batch = (size_t)u;
     } else if (name == "collectives") {
       if (!need_value() || (value != "rccl" && value != "loopback"))
         return "Illegal value '" + value + "' specified for flag 'collectives'";

@@ -28,6 +28,13 @@ struct Flags {
   int variant = -1;                     // tiled kernel variant (library option "variant"); -1: the default
   std::string pack = "auto";            // host | device | auto (device when the
                                         // reader threads per GPU are few, cuking_main.cc)
+  std::string decode = "auto";          // table: a whole table (or row group) decoded, then
+                                        // packed; stream: batches of triples packed as they
+                                        // are decoded (parquet_io.h StreamTriples); auto:
+                                        // stream for the host pack, table for the device pack
+  size_t decode_batch = 0;              // test hook: triples per batch of --decode=stream
+                                        // (0: 32 Ki for the host pack, a staging slot's
+                                        // worth for the device pack)
   std::string dump_bitset;              // diagnostic: write the packed host
                                         // bitset here and exit (no GPU used)
   // Several GPUs of this node share the shard (multi_gpu.h).  0 = the classic

@@ -4,6 +4,7 @@
 #include <parquet/api/reader.h>
 #include <parquet/api/writer.h>
 
+#include <algorithm>
 #include <memory>
 #include <sstream>
 
@@ -153,6 +154,110 @@ std::string ReadTriples(const std::string &path, int row_group, Triples *out) {
     out->row_idx.resize(w);
     out->col_idx.resize(w);
     out->n_alt_alleles.resize(w);
+    return "";
+  } catch (const std::exception &e) {  // cuking.cu:580-583
+    return std::string("Error reading ") + path + ": " + e.what();
+  }
+}
+
+namespace {
+
+// Up to `want` rows of one column into `values` (compact: nulls leave no gap);
+// `def` (nullable columns) receives one definition level per row.  Returns the
+// rows read; `*values_read` the non-null values among them.
+template <typename ReaderT, typename T>
+int64_t ReadRows(ReaderT *reader, bool nullable, int64_t want, T *values, int16_t *def,
+                 int64_t *values_read) {
+  int64_t rows = 0, vals = 0;
+  while (rows < want && reader->HasNext()) {
+    int64_t got_values = 0;
+    const int64_t got_levels = reader->ReadBatch(want - rows, nullable ? def + rows : nullptr,
+                                                 nullptr, values + vals, &got_values);
+    if (got_levels == 0 && got_values == 0) break;
+    rows += nullable ? got_levels : got_values;
+    vals += got_values;
+  }
+  *values_read = vals;
+  return rows;
+}
+
+}  // namespace
+
+std::string StreamTriples(const std::string &path, int row_group, size_t batch_rows,
+                          TripleScratch *scratch, TripleSink *sink) {
+  try {
+    std::unique_ptr<parquet::ParquetFileReader> file =
+        parquet::ParquetFileReader::OpenFile(path, /*memory_map=*/false);
+    const auto meta = file->metadata();
+    {
+      const std::string err = CheckSchema(*meta, path);
+      if (!err.empty()) return err;
+    }
+    if (row_group >= meta->num_row_groups()) {
+      std::ostringstream os;
+      os << "row group " << row_group << " outside the " << meta->num_row_groups() << " of "
+         << path;
+      return os.str();
+    }
+    if (batch_rows == 0) batch_rows = 1;
+    scratch->row_idx.resize(batch_rows);
+    scratch->col_idx.resize(batch_rows);
+    scratch->n_alt_alleles.resize(batch_rows);
+    scratch->def_levels.resize(batch_rows);
+    int64_t *const row = scratch->row_idx.data();
+    int64_t *const col = scratch->col_idx.data();
+    int32_t *const alt = scratch->n_alt_alleles.data();
+    int16_t *const def = scratch->def_levels.data();
+    const int g_begin = row_group < 0 ? 0 : row_group;
+    const int g_end = row_group < 0 ? meta->num_row_groups() : row_group + 1;
+    for (int g = g_begin; g < g_end; ++g) {
+      auto group = file->RowGroup(g);
+      const int64_t rows = group->metadata()->num_rows();
+      auto c0 = group->Column(0), c1 = group->Column(1), c2 = group->Column(2);
+      const char *names[3] = {"row_idx", "col_idx", "n_alt_alleles"};
+      parquet::ColumnReader *cols[3] = {c0.get(), c1.get(), c2.get()};
+      bool nullable[3];
+      for (int c = 0; c < 3; ++c) {
+        if (cols[c]->descr()->max_repetition_level() > 0)
+          return std::string(names[c]) + ": repeated columns are not supported in " + path;
+        nullable[c] = cols[c]->descr()->max_definition_level() > 0;
+      }
+      auto *r0 = static_cast<parquet::Int64Reader *>(cols[0]);
+      auto *r1 = static_cast<parquet::Int64Reader *>(cols[1]);
+      auto *r2 = static_cast<parquet::Int32Reader *>(cols[2]);
+      const int16_t alt_max_def = cols[2]->descr()->max_definition_level();
+      for (int64_t done = 0; done < rows;) {
+        const int64_t want = std::min<int64_t>((int64_t)batch_rows, rows - done);
+        int64_t v0 = 0, v1 = 0, v2 = 0;
+        if (ReadRows(r0, nullable[0], want, row, def, &v0) != want)
+          return "row_idx: column chunk shorter than its row group in " + path;
+        if (v0 != want) return "row_idx: null values are not allowed in this column in " + path;
+        if (ReadRows(r1, nullable[1], want, col, def, &v1) != want)
+          return "col_idx: column chunk shorter than its row group in " + path;
+        if (v1 != want) return "col_idx: null values are not allowed in this column in " + path;
+        if (ReadRows(r2, nullable[2], want, alt, def, &v2) != want)
+          return "n_alt_alleles: column chunk shorter than its row group in " + path;
+        size_t n = (size_t)want;
+        if (v2 != want) {
+          // Null genotypes (= missing): their rows leave the batch.  `alt` is compact
+          // already (v2 values), row / col are closed up over the same rows.
+          size_t w = 0;
+          for (int64_t r = 0; r < want; ++r) {
+            if (def[r] != alt_max_def) continue;
+            row[w] = row[r];
+            col[w] = col[r];
+            ++w;
+          }
+          if ((int64_t)w != v2) return "n_alt_alleles: definition levels and values disagree in " + path;
+          n = w;
+        }
+        if (n != 0) {
+          const std::string err = sink->Consume(row, col, alt, n);
+          if (!err.empty()) return err;
+        }
+        done += want;
+      }
+    }
     return "";
   } catch (const std::exception &e) {  // cuking.cu:580-583
     return std::string("Error reading ") + path + ": " + e.what();

@@ -27,6 +27,25 @@ struct Triples {
 // null n_alt_alleles drops the entry (= missing genotype).  Returns "" or the
 // error message.
 std::string ReadTriples(const std::string &path, int row_group, Triples *out);
+// The same table (or row group) in batches of at most `batch_rows` triples, handed to
+// `sink` as they are decoded: the three column readers advance in step, the batch
+// buffers (`scratch`, reused from call to call) stay in the cache, and no vector of a
+// whole column chunk -- 20 bytes per triple, first zero-filled, then written, then
+// read -- is ever allocated.  Same acceptance rules and messages as ReadTriples; null
+// genotypes are dropped before the sink sees the batch.  `sink` returns "" or an
+// error that ends the read.
+struct TripleSink {
+  virtual ~TripleSink() = default;
+  virtual std::string Consume(const int64_t *row_idx, const int64_t *col_idx,
+                              const int32_t *n_alt_alleles, size_t n) = 0;
+};
+struct TripleScratch {
+  std::vector<int64_t> row_idx, col_idx;
+  std::vector<int32_t> n_alt_alleles;
+  std::vector<int16_t> def_levels;
+};
+std::string StreamTriples(const std::string &path, int row_group, size_t batch_rows,
+                          TripleScratch *scratch, TripleSink *sink);
 // Number of row groups of a table (reads the footer only; validates the schema
 // like ReadTriples).
 std::string CountRowGroups(const std::string &path, int *num_row_groups);

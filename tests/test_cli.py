@@ -323,10 +323,21 @@ def test_host_threads_under_tsan(tmp_path, oracle):
 
 # ------------------------------------------------- decode + pack (CPU) ----
 def dump_bits(in_dir, tmp_path, n_stored, wps, *extra):
+    """The packed bitset of the host path -- through both forms of the decode (whole
+    tables; batches packed as they are decoded: the default, here also with batches of
+    97 triples so that they end inside pages, row groups and runs of nulls), which
+    must agree bit for bit."""
     dump = tmp_path / "bits.bin"
-    run_cli("--input_uri", in_dir, "--output_uri", tmp_path / "unused",
-            "--dump_bitset", dump, "--num_reader_threads=4", *extra, check=True)
-    return np.fromfile(dump, dtype=np.uint64).reshape(n_stored, wps)
+    got = {}
+    for mode in (("--decode=table",), ("--decode=stream",), ("--decode=stream", "--decode_batch=97"),
+                 ()):
+        run_cli("--input_uri", in_dir, "--output_uri", tmp_path / "unused",
+                "--dump_bitset", dump, "--num_reader_threads=4", *mode, *extra, check=True)
+        got[mode] = np.fromfile(dump, dtype=np.uint64).reshape(n_stored, wps)
+    first = got[("--decode=table",)]
+    for mode, bits in got.items():
+        assert np.array_equal(bits, first), mode
+    return first
 
 
 @pytest.mark.parametrize("layout", [
@@ -400,9 +411,10 @@ def test_null_genotypes_are_missing_and_bad_inputs_fail(tmp_path, oracle):
         for f in d.glob("*.parquet"):
             f.unlink()
         pq.write_table(table, d / "t.parquet")
-        p = run_cli("--input_uri", d, "--output_uri", tmp_path / "o", "--dump_bitset",
-                    tmp_path / "x.bin")
-        assert p.returncode == 1 and needle in p.stderr, p.stderr
+        for mode in ("table", "stream"):
+            p = run_cli("--input_uri", d, "--output_uri", tmp_path / "o", "--dump_bitset",
+                        tmp_path / "x.bin", f"--decode={mode}")
+            assert p.returncode == 1 and needle in p.stderr, (mode, p.stderr)
 
     expect_fail(pa.table({"row_idx": pa.array([0], pa.int64()),
                           "col_idx": pa.array([0], pa.int64()),
@@ -777,8 +789,11 @@ def test_hundred_million_triples_through_both_packs(tmp_path_factory):
     best, outputs = {}, {}
     for rep in range(2):
         for pack in ("host", "device"):
+            # (like with like: whole tables decoded, then packed, on both sides -- the host
+            #  pack's default is the streaming decode, the device pack's is not yet)
             p = run_cli("--input_uri", d / "in", "--output_uri", d / f"out_{pack}", f"--pack={pack}",
-                        "--num_reader_threads=16", "--kin_threshold=0.05", check=True)
+                        "--decode=table", "--num_reader_threads=16", "--kin_threshold=0.05",
+                        check=True)
             s_ = json.loads(p.stdout.strip().splitlines()[-1])
             assert s_["triples"] == triples and s_["pack"] == pack
             assert s_["decode_tasks"] > files            # row groups, not files
