@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <string>
 #include <tuple>
+#include <vector>
 
 #include "king_submatrix.h"
 
@@ -122,6 +123,30 @@ uint64_t cuking_bytes_per_pair(uint32_t words_per_sample) {
   return 2ull * words_per_sample * sizeof(uint64_t);
 }
 
+namespace {
+
+// Per reader thread: the AND masks of ONE 64-site word column, per stored sample.
+// Input tables are site-major (the Spark writer's order, mt_to_cuking_inputs.py:24-34:
+// all samples of a site, then the next site), so consecutive triples fall into the
+// same word of different samples' planes: 64 sites x n samples of them per column.
+// Collecting their bits here and clearing each (sample, plane) word once replaces
+// ~32 atomic read-modify-writes per word (15 ns per triple, most of the host
+// pack's time) by one.
+struct WordColumn {
+  std::vector<uint64_t> het, hom;   // bits to KEEP (all ones = untouched)
+  std::vector<uint8_t> dirty;
+  std::vector<uint32_t> touched;    // samples with dirty != 0, in arrival order
+  void Reserve(uint32_t samples) {
+    if (het.size() < samples) {
+      het.resize(samples, ~0ull);
+      hom.resize(samples, ~0ull);
+      dirty.resize(samples, 0);
+    }
+  }
+};
+
+}  // namespace
+
 cuking_status cuking_pack_host(const cuking_submatrix *sm,
                                uint32_t words_per_sample, uint64_t *bit_set,
                                const int64_t *row_idx, const int64_t *col_idx,
@@ -135,35 +160,74 @@ cuking_status cuking_pack_host(const cuking_submatrix *sm,
     __atomic_and_fetch(plane + (index >> 6), ~(1ull << (index & 63)),
                        __ATOMIC_RELAXED);
   };
+  // cuking.cu:675-703 per triple; `direct` = straight into the bitset (one atomic AND
+  // per bit, cuking.cu:317-323), otherwise through the word column.
+  thread_local WordColumn wc_of_thread;
+  WordColumn &wc = wc_of_thread;  // (one thread-local lookup per call, not per triple)
+  // (short calls, and tables that are not site-major -- detected below -- go direct)
+  bool direct = num_triples < 1024;
+  if (!direct) wc.Reserve(cuking_submatrix_num_samples(sm));
+  uint64_t *const keep_het = wc.het.data(), *const keep_hom = wc.hom.data();
+  uint8_t *const dirty = wc.dirty.data();
+  uint64_t column = ~0ull;      // word index the masks belong to
+  size_t flushes = 0;
+  auto flush = [&]() {
+    for (const uint32_t s : wc.touched) {
+      uint64_t *het = bit_set + (uint64_t)s * words_per_sample + column;
+      if (keep_het[s] != ~0ull) __atomic_and_fetch(het, keep_het[s], __ATOMIC_RELAXED);
+      if (keep_hom[s] != ~0ull) __atomic_and_fetch(het + plane_words, keep_hom[s], __ATOMIC_RELAXED);
+      keep_het[s] = keep_hom[s] = ~0ull;
+      dirty[s] = 0;
+    }
+    wc.touched.clear();
+    ++flushes;
+  };
   for (size_t t = 0; t < num_triples; ++t) {
     const int64_t col = col_idx[t];
     if (col < 0 || col > 0xFFFFFFFFll || !sm_contains(*sm, (uint32_t)col))
       continue;
     const int64_t row = row_idx[t];
-    if (row < 0 || (uint64_t)row >= plane_bits)
+    if (row < 0 || (uint64_t)row >= plane_bits) {
+      if (!direct) flush();
       return cuking_fail(CUKING_ERR_INVALID_ARGUMENT,
                   "row_idx %lld outside the %llu padded sites", (long long)row,
                   (unsigned long long)plane_bits);
-    uint64_t *het = bit_set + (uint64_t)sm_sample_offset(*sm, (uint32_t)col) *
-                                  words_per_sample;
-    uint64_t *hom = het + plane_words;
-    switch (n_alt_alleles[t]) {
-      case 0:
-        clear_bit(het, (uint64_t)row);
-        clear_bit(hom, (uint64_t)row);
-        break;
-      case 1:
-        clear_bit(hom, (uint64_t)row);
-        break;
-      case 2:
-        clear_bit(het, (uint64_t)row);
-        break;
-      default:
-        return cuking_fail(CUKING_ERR_FAILED_PRECONDITION,
-                    "Invalid value for n_alt_alleles (%d) encountered",
-                    n_alt_alleles[t]);
     }
+    const int32_t alt = n_alt_alleles[t];
+    if (alt < 0 || alt > 2) {
+      if (!direct) flush();
+      return cuking_fail(CUKING_ERR_FAILED_PRECONDITION,
+                  "Invalid value for n_alt_alleles (%d) encountered", alt);
+    }
+    const uint32_t sample = sm_sample_offset(*sm, (uint32_t)col);
+    if (direct) {
+      uint64_t *het = bit_set + (uint64_t)sample * words_per_sample;
+      if (alt != 1) clear_bit(het, (uint64_t)row);                // 0 and 2: not het
+      if (alt != 2) clear_bit(het + plane_words, (uint64_t)row);  // 0 and 1: not hom-alt
+      continue;
+    }
+    const uint64_t w = (uint64_t)row >> 6;
+    if (w != column) {
+      if (!wc.touched.empty()) flush();
+      column = w;
+      // Not site-major after all (a column change every few triples): the masks
+      // buy nothing, the rest of the call goes direct.
+      if (flushes >= 256 && t < 8 * flushes) {
+        direct = true;
+        --t;  // this triple again, on the direct path
+        continue;
+      }
+    }
+    if (!dirty[sample]) {
+      dirty[sample] = 1;
+      wc.touched.push_back(sample);
+    }
+    // (branch-free: a mask of all ones where the plane keeps its bit)
+    const uint64_t bit = 1ull << (row & 63);
+    keep_het[sample] &= ~(alt != 1 ? bit : 0ull);
+    keep_hom[sample] &= ~(alt != 2 ? bit : 0ull);
   }
+  if (!direct && !wc.touched.empty()) flush();
   return CUKING_OK;
 }
 

@@ -127,6 +127,58 @@ def test_pack_host_concurrent_threads(oracle):
     assert np.array_equal(bits, oracle.bitset_from_genotypes(geno))
 
 
+@pytest.mark.parametrize("k,shard", [(1, 0), (2, 1), (3, 4)])
+def test_pack_host_orders_of_the_input(oracle, k, shard):
+    """cuking_pack_host collects the bits of one 64-site word column per sample and clears
+    each word once when the table is site-major (the Spark writer's order), falls back to a
+    bit at a time when it is not: every order of the same triples gives the oracle's bitset
+    -- site-major, sample-major, shuffled, site-major with a shuffled stretch in the
+    middle -- and an error in the middle of a column leaves the thread's masks clean."""
+    rng = np.random.default_rng(11)
+    n, m = 61, 900                       # 15 word columns, the last one partial
+    geno = random_genotypes(rng, n, m, missing=0.1)
+    site, sample = np.nonzero(geno.T >= 0)            # site-major
+    alt = geno[sample, site].astype(np.int32)
+    assert len(site) > 40000
+    sm = cuking_amd.Submatrix(n, k, shard)
+    osm = oracle.submatrix(n, k, shard)
+    exp = oracle.new_bitset(osm, m)
+    oracle.pack(osm, exp, site, sample, alt)
+    orders = {"site-major": np.arange(len(site)),
+              "sample-major": np.lexsort((site, sample)),
+              "shuffled": rng.permutation(len(site))}
+    mixed = np.arange(len(site))
+    mixed[20000:30000] = rng.permutation(mixed[20000:30000])
+    orders["site-major with a shuffled stretch"] = mixed
+    for name, o in orders.items():
+        bits = cuking_amd.new_host_bitset(sm, m)
+        cuking_amd.pack_host(sm, bits, site[o], sample[o], alt[o])
+        assert np.array_equal(bits, exp), name
+    # in two calls that cut a word column in two
+    bits = cuking_amd.new_host_bitset(sm, m)
+    cuking_amd.pack_host(sm, bits, site[:12345], sample[:12345], alt[:12345])
+    cuking_amd.pack_host(sm, bits, site[12345:], sample[12345:], alt[12345:])
+    assert np.array_equal(bits, exp)
+    # an invalid genotype / site in the middle: reported, and what the thread had collected
+    # so far does not leak into the next call
+    for bad_alt, bad_site, status in ((3, None, _lib.ERR_FAILED_PRECONDITION),
+                                      (None, 64 * bits.shape[1] // 2, _lib.ERR_INVALID_ARGUMENT)):
+        a2, s2 = alt.copy(), site.copy()
+        at = int(np.flatnonzero([osm.i_begin <= c < osm.i_end or osm.j_begin <= c < osm.j_end
+                                 for c in sample[5000:5200]])[0]) + 5000
+        if bad_alt is not None:
+            a2[at] = bad_alt
+        else:
+            s2[at] = bad_site
+        scratch = cuking_amd.new_host_bitset(sm, m)
+        with pytest.raises(cuking_amd.CukingError) as e:
+            cuking_amd.pack_host(sm, scratch, s2, sample, a2)
+        assert e.value.status == status
+        bits = cuking_amd.new_host_bitset(sm, m)
+        cuking_amd.pack_host(sm, bits, site, sample, alt)
+        assert np.array_equal(bits, exp)
+
+
 def test_pack_host_errors():
     sm = cuking_amd.Submatrix(3)
     bits = cuking_amd.new_host_bitset(sm, 64)
