@@ -398,11 +398,17 @@ def all_pairs_king_staged(ops, num_samples: int, tile: int, bit_sets,
         rank, world = 0, 1
     steps = staged_schedule(num_samples, tile, world, rank, num_chunks)
 
-    ops.begin()
+    # (begin() reserves the workspace: device allocations that can fail.  A rank that
+    #  fails here still takes part in every broadcast and in the gather, where its
+    #  status makes every rank raise -- it must not leave the others waiting.)
+    error = None
+    try:
+        ops.begin()
+    except Exception as e:  # noqa: BLE001 - raised on every rank below
+        error = e
     # All chunk broadcasts are enqueued up front; they complete in order.
     works = [dist.broadcast(bit_sets[c0:c1], src=src, group=group, async_op=True)
              for (c0, c1), _ in steps] if use_dist else []
-    error = None
     for k, ((c0, c1), rect) in enumerate(steps):
         if use_dist and rank != src:
             works[k].wait()        # nccl: the current stream waits, not the host
@@ -460,8 +466,18 @@ class GpuStagedOps:
             import torch
             self.ctx.reserve(self.sm, self.wps, [torch.cuda.current_stream()] + self.streams)
             self._reserved = True
+            self._at_reserve = (self.ctx.get_option("workspace_allocations"),
+                                self.ctx.get_option("host_syncs"))
         self.index_flag.zero_()
         self.launches = 0
+
+    def after_reserve(self):
+        """(device allocations, host-side waits) the library has made for this context
+        since begin() reserved its workspace -- i.e. while broadcasts may have been in
+        flight: both must read 0."""
+        a0, s0 = getattr(self, "_at_reserve", (0, 0))
+        return (self.ctx.get_option("workspace_allocations") - a0,
+                self.ctx.get_option("host_syncs") - s0)
 
     def prepare(self, s0: int, s1: int):
         self.ctx.prepare_samples(self.sm, self.wps, self.bits, s0, s1)

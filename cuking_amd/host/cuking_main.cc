@@ -701,6 +701,7 @@ Status Run(const Flags &flags) {
     in.calibration_tiles = flags.calibration_tiles;
     in.inject_failure_rank = flags.inject_failure_rank;
     in.inject_failure_phase = flags.inject_failure_phase;
+    in.phase_timeout_seconds = flags.phase_timeout_seconds;
     cuking_host::MultiGpuOutput mg;
     std::string code;
     const std::string err = cuking_host::RunMultiGpu(in, &mg, &code);

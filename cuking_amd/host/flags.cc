@@ -72,7 +72,11 @@ std::string Usage() {
          "2 % of a GPU's share)\n"
          "  --collectives=rccl|loopback  loopback is for tests: the ranks of --num_gpus=N "
          "share ONE GPU, copies instead of RCCL\n"
-         "  --inject_failure=R:PHASE  tests: rank R fails in phase setup|compute|gather\n"
+         "  --inject_failure=R:PHASE  tests: rank R fails in phase setup|compute|gather, or "
+         "never comes back from it (hang_compute|hang_gather)\n"
+         "  --phase_timeout_seconds=T  --num_gpus runs: a rank that stays in one phase (a "
+         "collective, a phase barrier, a wait for its GPU) longer than T seconds ends the "
+         "process with exit code 1, naming every rank's phase (default 1800; 0 = no limit)\n"
          "  --synthetic=N,M[,SEED] instead of --input_uri: synthetic cohort of N samples x M "
          "sites generated on the GPU (founders + planted relatives)\n"
          "  --print_schedule       diagnostic: print the multi-GPU schedule (JSON) and "
@@ -239,11 +243,19 @@ std::string ParseFlags(int argc, char **argv, Flags *flags) {
       if (colon == std::string::npos || !ParseUnsigned(value.substr(0, colon), 63, &r))
         return "Illegal value '" + value + "' specified for flag 'inject_failure'";
       const std::string phase = value.substr(colon + 1);
-      if (phase != "setup" && phase != "compute" && phase != "gather")
+      if (phase != "setup" && phase != "compute" && phase != "gather" &&
+          phase != "hang_compute" && phase != "hang_gather")
         return "Illegal value '" + value + "' specified for flag 'inject_failure'";
       flags->inject_failure = value;
       flags->inject_failure_rank = (int)r;
       flags->inject_failure_phase = phase;
+    } else if (name == "phase_timeout_seconds") {
+      errno = 0;
+      char *end = nullptr;
+      const double t = need_value() ? strtod(value.c_str(), &end) : -1.0;
+      if (value.empty() || end == value.c_str() || *end != '\0' || errno != 0 || !(t >= 0))
+        return "Illegal value '" + value + "' specified for flag 'phase_timeout_seconds'";
+      flags->phase_timeout_seconds = t;
     } else {
       return "Unknown command line flag '" + name + "'";
     }

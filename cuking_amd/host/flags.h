@@ -50,9 +50,15 @@ struct Flags {
   bool calibrate = true;
   uint64_t calibration_tiles = 0;       // per rank; 0 = automatic
   std::string collectives = "rccl";     // rccl | loopback (TEST ONLY: rank threads share one GPU)
-  std::string inject_failure;           // TEST ONLY: "rank:phase" (setup | compute | gather)
+  std::string inject_failure;           // TEST ONLY: "rank:phase" (setup | compute | gather fail;
+                                        // hang_compute | hang_gather: the rank never comes back)
   int inject_failure_rank = -1;
   std::string inject_failure_phase;
+  // Wall-clock limit of every phase of a --num_gpus run (multi_gpu.cc: a rank that
+  // sits in one phase -- inside a collective, at a phase barrier, waiting for its
+  // device -- longer than this ends the process with exit code 1 and a message that
+  // names every rank's phase); 0 = no limit.
+  double phase_timeout_seconds = 1800;
   // "N,M[,seed]": no input tables; the cohort of synth_plan.h is generated on
   // the GPU (BASELINE configs without their 1e9 .. 1.5e11-row Parquet form).
   std::string synthetic;

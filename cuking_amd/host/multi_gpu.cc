@@ -8,11 +8,16 @@
 #endif
 #include <hip/hip_runtime_api.h>
 
+#include <unistd.h>
+
 #include <atomic>
 #include <barrier>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -46,6 +51,17 @@ struct Shared {
   bool agreed_failed = false;
   std::mutex mu;
   std::string error, code;
+  // The phase every rank is in and since when (watchdog below).
+  struct Watch {
+    std::atomic<const char *> phase{nullptr};  // nullptr: not started / through
+    std::atomic<double> since{0};
+  };
+  std::unique_ptr<Watch[]> watch;
+
+  void Enter(int rank, const char *phase) {
+    watch[rank].since.store(Now());
+    watch[rank].phase.store(phase);
+  }
 
   void Fail(const std::string &c, const std::string &msg) {
     std::lock_guard<std::mutex> lock(mu);
@@ -55,6 +71,60 @@ struct Shared {
     }
     failed.store(true);
   }
+};
+
+// Wall-clock watchdog of a --num_gpus run.  The ranks block in places nobody can
+// cancel from outside -- inside an RCCL call that waits for a peer, at a phase
+// barrier, in a wait for a device whose collective kernel never ends -- so a rank
+// that stays in ONE phase longer than the limit ends the process: the reference's
+// error line (cuking.cu:889-892) with every rank's phase, exit code 1.
+class Watchdog {
+ public:
+  Watchdog(Shared *sh, int world, double limit) : sh_(sh), world_(world), limit_(limit) {
+    if (limit_ > 0) thread_ = std::thread([this] { Loop(); });
+  }
+  ~Watchdog() {
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    if (thread_.joinable()) thread_.join();
+  }
+
+ private:
+  void Loop() {
+    std::unique_lock<std::mutex> lock(mu_);
+    while (!cv_.wait_for(lock, std::chrono::milliseconds(50), [this] { return stop_; })) {
+      const double now = Now();
+      int late = -1;
+      for (int r = 0; r < world_; ++r)
+        if (sh_->watch[r].phase.load() != nullptr && now - sh_->watch[r].since.load() > limit_ &&
+            (late < 0 || sh_->watch[r].since.load() < sh_->watch[late].since.load()))
+          late = r;
+      if (late < 0) continue;
+      std::string msg = "\nError: DEADLINE_EXCEEDED: rank " + std::to_string(late) +
+                        " has been in phase '" + sh_->watch[late].phase.load() + "' for " +
+                        std::to_string((int)(now - sh_->watch[late].since.load())) +
+                        " s (--phase_timeout_seconds=" + std::to_string((int)limit_) +
+                        "); every rank:";
+      for (int r = 0; r < world_; ++r) {
+        const char *ph = sh_->watch[r].phase.load();
+        msg += " [" + std::to_string(r) + "] " + (ph ? ph : "through") +
+               (ph ? " " + std::to_string((int)(now - sh_->watch[r].since.load())) + " s" : "");
+      }
+      msg += "\n";
+      (void)!write(2, msg.data(), msg.size());
+      _exit(1);  // (no destructors: the stuck threads hold the devices)
+    }
+  }
+  Shared *sh_;
+  int world_;
+  double limit_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  bool stop_ = false;
+  std::thread thread_;
 };
 
 struct Snapshot {
@@ -154,7 +224,12 @@ int64_t Option(cuking_ctx *ctx, const char *key) {
 // taking part (with nothing to contribute) and the failure is agreed on at the
 // phase barriers (Shared::agreed_failed), so nobody is left waiting inside RCCL
 // or at a barrier for a rank that gave up.
+void RankBody(Shared *sh, PhaseBarrier *barrier, int rank);
 void RankMain(Shared *sh, PhaseBarrier *barrier, int rank) {
+  RankBody(sh, barrier, rank);
+  sh->Enter(rank, nullptr);  // through (also on the early exits of an agreed failure)
+}
+void RankBody(Shared *sh, PhaseBarrier *barrier, int rank) {
   const MultiGpuInput &in = *sh->in;
   const int world = in.num_gpus;
   Collectives *coll = sh->coll;
@@ -172,6 +247,11 @@ void RankMain(Shared *sh, PhaseBarrier *barrier, int rank) {
       ok = false;
     }
   };
+  // TEST ONLY: the rank never comes back from `phase` (the watchdog ends the job).
+  auto inject_hang = [&](const char *phase) {
+    if (rank == in.inject_failure_rank && in.inject_failure_phase == std::string("hang_") + phase)
+      for (;;) std::this_thread::sleep_for(std::chrono::seconds(1));
+  };
   // Agreement at the end of a phase: true = somebody failed, everybody stops.
   auto phase_failed = [&]() {
     barrier->arrive_and_wait();
@@ -182,6 +262,7 @@ void RankMain(Shared *sh, PhaseBarrier *barrier, int rank) {
   };
 
   // ---- setup ----------------------------------------------------------------
+  sh->Enter(rank, "setup (context, streams, buffers, workspace reservation)");
   RANK_HIP(hipSetDevice(st.device));
   if (ok) RANK_ABI(cuking_ctx_create(st.device, &st.ctx));
   if (ok)
@@ -211,6 +292,12 @@ void RankMain(Shared *sh, PhaseBarrier *barrier, int rank) {
   if (ok) RANK_HIP(hipEventCreate(&st.cal_begin));
   if (ok) RANK_HIP(hipEventCreate(&st.cal_end));
   if (ok) RANK_HIP(hipMemsetAsync(st.d_counters, 0, 2 * sizeof(uint32_t), st.compute));
+  // (a rank that fails before it has a rate contributes 0 to the rate exchange)
+  if (ok) RANK_HIP(hipMemsetAsync(st.d_rate, 0, sizeof(double), st.compute));
+  // Simple schedule: the bitset does not change once it has arrived, so the block
+  // is converted ONCE -- in front of the calibration launch, whose timed range
+  // then holds the pair kernel only -- and the main launch reuses the layout.
+  if (ok && tiled && !sh->staged) RANK_ABI(cuking_ctx_set_option(st.ctx, "reuse_prepared", 1));
   // The kernel layout of the whole block, the tile prefix and the compute
   // stream's split slab, NOW: once the first broadcast is enqueued no rank may
   // allocate or wait for its device (a blocking allocation beside in-flight
@@ -225,6 +312,7 @@ void RankMain(Shared *sh, PhaseBarrier *barrier, int rank) {
   if (phase_failed()) return;  // nobody has issued a collective yet
 
   // ---- exchange step 1 + compute ---------------------------------------------
+  sh->Enter(rank, "exchange 1 + compute (broadcasts and kernels enqueued)");
   const double t0 = Now();
   // (staged schedule: --rank_weights deals the tile rows in proportion; the
   //  calibration launch belongs to the simple schedule)
@@ -296,6 +384,13 @@ void RankMain(Shared *sh, PhaseBarrier *barrier, int rank) {
       // times a small range of its own, the rates are exchanged, and the rest
       // of the enumeration is cut in proportion (schedule.h).  Same decision
       // and same collective on every rank.
+      sh->Enter(rank, "calibration launch + rate exchange");
+      // (an empty tile range converts the block and launches nothing: the timed
+      //  range below is the pair kernel alone)
+      if (ok)
+        RANK_ABI(cuking_compute_king_tiles(st.ctx, &in.sm, wps, st.d_bits, 0, 0, in.kin_threshold,
+                                           in.max_results, st.d_results, st.d_counters,
+                                           st.d_counters + 1, st.compute));
       if (ok) RANK_HIP(hipEventRecord(st.cal_begin, st.compute));
       launch_tiles((uint64_t)rank * cal_tiles, (uint64_t)(rank + 1) * cal_tiles);
       if (ok) RANK_HIP(hipEventRecord(st.cal_end, st.compute));
@@ -325,6 +420,8 @@ void RankMain(Shared *sh, PhaseBarrier *barrier, int rank) {
     }
   }
   inject("compute");
+  sh->Enter(rank, "exchange 2: counts (all-gather, wait for this rank's kernels)");
+  inject_hang("compute");
 
   // ---- exchange step 2: counts, then records ---------------------------------
   RANK_COLL(coll->AllGather(rank, st.d_counters, st.d_all, 2 * sizeof(uint32_t), st.compute));
@@ -353,6 +450,8 @@ void RankMain(Shared *sh, PhaseBarrier *barrier, int rank) {
   }
   inject("gather");
   if (phase_failed()) return;  // (a failure here is agreed on before anybody sends)
+  sh->Enter(rank, "exchange 2: records (gather on rank 0)");
+  inject_hang("gather");
   {
     std::vector<uint64_t> bytes(world), offset(world);
     for (int r = 0; r < world; ++r) {
@@ -395,7 +494,9 @@ void RankMain(Shared *sh, PhaseBarrier *barrier, int rank) {
       sh->out->calibration_tiles = cal_tiles;
     }
   }
-  barrier->arrive_and_wait();  // nobody tears down while a peer still receives
+  sh->Enter(rank, "last barrier (nobody tears down while a peer still receives)");
+  barrier->arrive_and_wait();
+  sh->Enter(rank, nullptr);
 }
 
 }  // namespace
@@ -449,6 +550,9 @@ std::string RunMultiGpu(const MultiGpuInput &in, MultiGpuOutput *out, std::strin
   std::unique_ptr<Collectives> coll = loopback ? MakeLoopbackCollectives() : MakeRcclCollectives();
   sh.coll = coll.get();
   out->collectives = coll->name();
+  sh.watch.reset(new Shared::Watch[in.num_gpus]);
+  Watchdog watchdog(&sh, in.num_gpus, in.phase_timeout_seconds);
+  for (int r = 0; r < in.num_gpus; ++r) sh.Enter(r, "communicator set-up (InitAll)");
   const auto init_t0 = std::chrono::steady_clock::now();
   const std::string init_error = coll->InitAll(devices);
   out->comm_init_seconds =

@@ -40,8 +40,14 @@ struct MultiGpuInput {
   std::vector<double> rank_weights;
   bool calibrate = true;
   uint64_t calibration_tiles = 0;  // per rank; 0 = schedule.h CalibrationTiles()
+  // A rank that stays in one phase longer than this (seconds; 0 = no limit) ends
+  // the PROCESS: "\nError: DEADLINE_EXCEEDED: ..." with every rank's phase on stderr,
+  // exit code 1.  (Threads stuck inside a collective or a device wait cannot be
+  // cancelled, so there is no status to return.)
+  double phase_timeout_seconds = 0;
   // TEST ONLY: rank `inject_failure_rank` reports a failure in phase "setup",
-  // "compute" or "gather" (exercises the agreement on failures).
+  // "compute" or "gather" (exercises the agreement on failures), or never comes
+  // back from it ("hang_compute", "hang_gather": exercises the watchdog).
   int inject_failure_rank = -1;
   std::string inject_failure_phase;
 };

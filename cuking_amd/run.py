@@ -219,6 +219,7 @@ def main(argv=None) -> int:
         if pack_error is not None:
             raise RuntimeError(str(pack_error))
         t1 = time.perf_counter()
+        after_reserve = lambda: (0, 0)    # noqa: E731 - (allocations, host waits) since the reservation
         if sm.i_begin == sm.j_begin:
             # Diagonal block (the whole cohort when split_factor = 1): row bands
             # per rank, chunked broadcast overlapped with the kernel.
@@ -226,6 +227,7 @@ def main(argv=None) -> int:
             ops = GpuStagedOps(ctx, local, wps, bits, args.kin_threshold, args.max_results)
             recs, _ = all_pairs_king_staged(ops, stored, ctx.tile_samples(), bits,
                                             num_chunks=args.chunks)
+            after_reserve = ops.after_reserve
             if recs is not None:  # local -> global sample indices
                 recs["sample_i"] += sm.i_begin
                 recs["sample_j"] += sm.j_begin
@@ -243,9 +245,23 @@ def main(argv=None) -> int:
                 return results, min(count, args.max_results), int(ovf)
 
             if world > 1:
+                # workspace before the first collective (cuking_ctx_reserve), as in the
+                # staged pass
+                ctx.reserve(sm, wps, [torch.cuda.current_stream()])
+                at = (ctx.get_option("workspace_allocations"), ctx.get_option("host_syncs"))
+                after_reserve = lambda: (ctx.get_option("workspace_allocations") - at[0],  # noqa: E731
+                                         ctx.get_option("host_syncs") - at[1])
                 recs, _ = all_pairs_king(compute_tiles, ctx.num_tiles(sm), bits)
             else:
                 recs = ctx.run(sm, wps, bits, args.kin_threshold, args.max_results)
+        # every rank's library-side allocations / host waits after its reservation
+        # (must be 0: nothing blocks beside in-flight collectives)
+        mine = torch.tensor(after_reserve(), dtype=torch.int64, device=dev)
+        per_rank = [mine]
+        if world > 1:
+            per_rank = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(per_rank, mine)
+        per_rank = [t.tolist() for t in per_rank]
         if rank == 0:
             dt = time.perf_counter() - t1
             out = out_dir / f"part-{args.shard_index:05d}.snappy.parquet"
@@ -253,6 +269,8 @@ def main(argv=None) -> int:
             pairs = sm.NumPairs()
             print(json.dumps({"pairs": pairs, "results": int(len(recs)), "gpus": world,
                               "compute_seconds": dt,
+                              "allocations_after_reserve": [int(x[0]) for x in per_rank],
+                              "host_syncs_after_reserve": [int(x[1]) for x in per_rank],
                               "pairs_per_second": pairs / dt if dt > 0 else 0.0}), flush=True)
         rc = 0
     except cuking_amd.ResourceExhaustedError as e:

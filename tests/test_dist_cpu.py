@@ -294,6 +294,15 @@ def _failure_worker(rank, world, port, mode, out_path):
                 def compute_rect(self, rows, cols): pass
                 def finish(self): return local, 0, 0
             all_pairs_king_staged(Ops(), 200, 64, bits, num_chunks=3)
+        elif mode == "staged_begin":       # the workspace reservation itself fails
+            class Ops:
+                def begin(self):
+                    if bad:
+                        raise RuntimeError("injected kernel failure")
+                def prepare(self, s0, s1): pass
+                def compute_rect(self, rows, cols): pass
+                def finish(self): return local, 0, 0
+            all_pairs_king_staged(Ops(), 200, 64, bits, num_chunks=3)
         else:
             pipe = PipelinedGather(fast_rows=8)
             flag = torch.tensor([2, 0], dtype=torch.int32)
@@ -307,7 +316,8 @@ def _failure_worker(rank, world, port, mode, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["simple", "simple_folded", "device_folded", "staged", "pipelined"])
+@pytest.mark.parametrize("mode", ["simple", "simple_folded", "device_folded", "staged",
+                                  "staged_begin", "pipelined"])
 @pytest.mark.timeout(120)
 def test_failure_on_one_rank_raises_on_all(tmp_path, mode):
     """SURVEY section 5 'per-rank error -> abort all ranks': an exception on one
