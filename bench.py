@@ -108,8 +108,9 @@ def parse_args():
                     help="workload behind `value`; default c2 at every N (strong scaling)")
     ap.add_argument("--extra-configs", default=None,
                     help="comma list of further configs measured after the headline and "
-                         "reported under other_configs (default c1,c3 with the default "
-                         "headline, + c4 from 4 GPUs on; 'none' disables)")
+                         "reported under other_configs (default c0,c1,c3 with the default "
+                         "headline -- c0 = the real-input path through the C++ host, N = 1 "
+                         "only --, + c4 from 4 GPUs on; 'none' disables)")
     ap.add_argument("--samples", type=int, default=0, help="override N samples")
     ap.add_argument("--sites", type=int, default=0, help="override the site count")
     ap.add_argument("--kin-threshold", type=float, default=None)
@@ -162,6 +163,9 @@ def parse_args():
     ap.add_argument("--no-h2d-pass", action="store_true",
                     help="skip timing the host-to-device copy of the bitset "
                          "(value_including_h2d)")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
+                    help="library option set on the context (cuking_ctx_set_option), e.g. "
+                         "filter_check1=0; repeatable (A/B runs)")
     ap.add_argument("--seed", type=int, default=20240229)
     return ap.parse_args()
 
@@ -345,7 +349,8 @@ def filter_counters(ctx):
     the filter variant (diagnostic options of the library: they wait for the device)."""
     if ctx.get_option("variant") != 7:
         return None
-    return ctx.get_option("filter_candidates"), ctx.get_option("filter_dense_quadrants")
+    return (ctx.get_option("filter_candidates"), ctx.get_option("filter_dense_quadrants"),
+            ctx.get_option("filter_early_exits"))
 
 
 def records_of(results, count):
@@ -470,10 +475,15 @@ def single_gpu_workload(args, ctx, n, m, thr, steps, warmup, local_rank, clock_p
                 filter=(None if filt0 is None else
                         {"candidates_per_pass": (filt1[0] - filt0[0]) / steps,
                          "dense_quadrants_per_pass": (filt1[1] - filt0[1]) / steps,
+                         "tiles_left_at_the_check_point_per_pass": (filt1[2] - filt0[2]) / steps,
+                         "tiles_per_pass": ctx.num_tiles(sm),
                          "records_per_pass": len(recs),
                          "note": "filter variant: pairs its bound let through to the exact "
                                  "recount, 128 x 128 quadrants handed to the four-product "
-                                 "kernel instead, and the records of a pass"}))
+                                 "kernel instead, 256 x 256 tiles that left at the rigorous "
+                                 "check point inside the k loop (no pair of theirs could still "
+                                 "become a candidate: king_filter.hip), and the records of a "
+                                 "pass"}))
 
 
 def dist_workload(args, env, ctx, key, n, m, thr, steps, warmup, headline):
@@ -732,6 +742,161 @@ def dist_workload(args, env, ctx, key, n, m, thr, steps, warmup, headline):
     return out
 
 
+def genotypes_from_bits(bits, num_sites):
+    """int8 [samples, sites] (0 / 1 / 2 alternate alleles, -1 missing) from a
+    reference-layout bitset (cuking.cu:507-523: het plane, hom-alt plane, both = missing)."""
+    import numpy as np
+    half = bits.shape[1] // 2
+    het = np.unpackbits(np.ascontiguousarray(bits[:, :half]).view(np.uint8), axis=1,
+                        bitorder="little")[:, :num_sites].astype(bool)
+    hom = np.unpackbits(np.ascontiguousarray(bits[:, half:2 * half]).view(np.uint8), axis=1,
+                        bitorder="little")[:, :num_sites].astype(bool)
+    geno = np.zeros(het.shape, dtype=np.int8)
+    geno[het & ~hom] = 1
+    geno[hom & ~het] = 2
+    geno[het & hom] = -1
+    return geno
+
+
+def run_cuking(in_dir, out_dir, threads, *extra):
+    """One run of the C++ host (cuking_amd/bin/cuking) as a child process: wall seconds
+    and its JSON summary line."""
+    import subprocess
+    cli = ROOT / "cuking_amd" / "bin" / "cuking"
+    t0 = time.perf_counter()
+    p = subprocess.run([str(cli), "--input_uri", str(in_dir), "--output_uri", str(out_dir),
+                        f"--num_reader_threads={threads}", *extra],
+                       capture_output=True, text=True, timeout=900)
+    wall = time.perf_counter() - t0
+    if p.returncode != 0:
+        raise SystemExit(f"cuking failed on the real-input path: {p.stderr[-1500:]}")
+    return wall, json.loads(p.stdout.strip().splitlines()[-1])
+
+
+def real_input_path(args, ctx, local_rank):
+    """BASELINE configs[0]: 1k samples x 10k sites as REAL input -- 8 zstd Parquet files
+    with OPTIONAL columns in a Spark-style directory (cuking_amd/inputs.py = the layout of
+    mt_to_cuking_inputs.py:26-47) -- end to end through the C++ host `cuking`
+    (cuking.cu:435-882: list, decode, pack, kernel, sort, Snappy Parquet): wall seconds,
+    triples/s of decode + pack, the split the binary reports, the records compared with
+    the CPU oracle's, and the oracle's own time for the pair pass beside it.  Then, on
+    boxes that expose at least 8 hardware threads, a larger real-Parquet point (2000
+    samples x 50000 sites = 1e8 triples, 8 files of several row groups) through the host
+    pack and the pipelined device pack."""
+    import shutil
+    import tempfile
+    import numpy as np
+    import pyarrow.parquet as pq
+    import torch
+    import cuking_amd
+    from concurrent.futures import ProcessPoolExecutor
+    from cuking_amd.inputs import write_input_tables
+    from cuking_amd.synth import cohort_to_device, plan_cohort
+    from oracle import pyoracle
+    cpus = len(os.sched_getaffinity(0))
+    threads = max(1, min(16, cpus))
+    n, m, thr = 1000, 10_000, 0.05
+    d = Path(tempfile.mkdtemp(prefix="cuking_c0_"))
+    try:
+        cohort = plan_cohort(n, args.seed)
+        kind, pa, pb = cohort_to_device(cohort, local_rank)
+        bits = ctx.synth_bitset(args.seed, kind, pa, pb, 0, n, m)
+        torch.cuda.synchronize()
+        host_bits = np.ascontiguousarray(bits.cpu().numpy().view(np.uint64))
+        del bits
+        geno = genotypes_from_bits(host_bits, m)
+        ids = [f"S{k:07d}" for k in range(n)]
+        t0 = time.perf_counter()
+        write_input_tables(d / "in", geno, ids, num_files=8, compression="zstd", nullable=True,
+                           spark_layout=True)
+        generate_s = time.perf_counter() - t0
+        parquet_bytes = sum(p.stat().st_size for p in (d / "in").glob("*.parquet"))
+        runs = []
+        for rep in range(3):                      # (the first run pages the binary and the files in)
+            wall, summ = run_cuking(d / "in", d / f"out{rep}", threads, f"--kin_threshold={thr}")
+            runs.append((wall, summ))
+        wall, summ = min(runs[1:], key=lambda r: r[0])
+        # the CPU oracle on the same bitset: its records against the file's, and its time
+        pyoracle.compute(pyoracle.submatrix(64), host_bits[:64], thr, 1 << 16, threads=threads)
+        t0 = time.perf_counter()
+        exp, ovf, _ = pyoracle.compute(pyoracle.submatrix(n), host_bits, thr, 1 << 20,
+                                       threads=threads)
+        oracle_s = time.perf_counter() - t0
+        t = pq.read_table(d / "out2" / "part-00000.snappy.parquet")
+        same = (t.num_rows == len(exp) and
+                t.column("i").to_pylist() == [ids[x] for x in exp["sample_i"]] and
+                t.column("j").to_pylist() == [ids[x] for x in exp["sample_j"]] and
+                np.array_equal(t.column("kin").to_numpy().view(np.uint32), exp["kin"].view(np.uint32))
+                and all(np.array_equal(t.column(c).to_numpy().astype(np.uint32), exp[c])
+                        for c in ("ibs0", "ibs1", "ibs2")))
+        if not same and not args.no_check:
+            raise SystemExit("PARITY FAILURE: configs[0] through cuking differs from the CPU oracle")
+        out = {
+            "workload": "BASELINE configs[0]: 1k samples x 10k sites as real input (8 zstd "
+                        "Parquet files, OPTIONAL columns, Spark-style directory) through "
+                        "cuking_amd/bin/cuking, kin-threshold 0.05",
+            "wall_seconds": wall, "triples": summ["triples"], "parquet_MB": parquet_bytes / 1e6,
+            "read_pack_seconds": summ["read_pack_seconds"],
+            "triples_per_second": summ["triples_per_second"],
+            "decode_thread_seconds": summ["decode_thread_seconds"],
+            "pack_thread_seconds": summ["pack_thread_seconds"],
+            "kernel_seconds": summ["kernel_seconds"], "pack": summ["pack"],
+            "reader_threads": threads, "hardware_threads_visible": cpus,
+            "results": summ["results"], "pairs": summ["pairs"],
+            "checks": "output file's records identical to the CPU oracle's (ids, kin bits, IBS0/1/2)",
+            "wall_seconds_all_runs": [r[0] for r in runs],
+            "cpu_oracle": {"pair_pass_seconds": oracle_s, "threads": threads,
+                           "value": summ["pairs"] / oracle_s, "unit": "sample-pairs/s",
+                           "what": "oracle/king_oracle.c on the same packed bitset (pair pass only: "
+                                   "no decode, no pack)"},
+            "input_generation_seconds": generate_s,
+        }
+        if cpus >= 8:
+            sys.path.insert(0, str(ROOT / "tools"))
+            import cli_timing
+            n2, m2, files = 2000, 50_000, 8
+            big = d / "big"
+            big.mkdir()
+            (big / "metadata.json").write_text(json.dumps(
+                {"num_sites": m2, "samples": [f"S{k:07d}" for k in range(n2)]}))
+            bounds = np.linspace(0, m2, files + 1).astype(int)
+            jobs = [(str(big), f, int(bounds[f]), int(bounds[f + 1]), n2, 1, 2_000_000)
+                    for f in range(files)]
+            t0 = time.perf_counter()
+            with ProcessPoolExecutor(min(8, cpus)) as ex:
+                triples = sum(ex.map(cli_timing.write_part, jobs))
+            gen2 = time.perf_counter() - t0
+            point = {"workload": f"{n2} samples x {m2} sites as real input ({files} zstd files of "
+                                 "several row groups)", "triples": triples,
+                     "parquet_MB": sum(p.stat().st_size for p in big.glob("*.parquet")) / 1e6,
+                     "reader_threads": threads, "input_generation_seconds": gen2}
+            files_out = {}
+            for pack in ("host", "device"):
+                best = None
+                for rep in range(2):
+                    w, s2 = run_cuking(big, d / f"big_{pack}", threads, f"--pack={pack}",
+                                       "--kin_threshold=0.05")
+                    if best is None or s2["read_pack_seconds"] < best[1]["read_pack_seconds"]:
+                        best = (w, s2)
+                files_out[pack] = (d / f"big_{pack}" / "part-00000.snappy.parquet").read_bytes()
+                point[pack + "_pack"] = {k: best[1][k] for k in
+                                         ("read_pack_seconds", "triples_per_second",
+                                          "decode_thread_seconds", "pack_thread_seconds",
+                                          "kernel_seconds", "decode_tasks")}
+                point[pack + "_pack"]["wall_seconds"] = best[0]
+            if files_out["host"] != files_out["device"] and not args.no_check:
+                raise SystemExit("PARITY FAILURE: host-packed and device-packed outputs differ")
+            point["checks"] = "host-packed and device-packed output files identical"
+            out["larger_point"] = point
+        else:
+            out["larger_point"] = None
+            out["larger_point_note"] = (f"skipped: {cpus} hardware threads visible (generating and "
+                                        "decoding 1e8 triples is sized for at least 8)")
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def visible_gpus(timeout=120.0):
     """GPUs HIP shows to this environment, counted in a CHILD process (ctypes ->
     libcuking_amd.so -> hipGetDeviceCount): the caller must not initialise the GPU
@@ -883,6 +1048,9 @@ def main():
         ctx.set_option("split_wgs", args.split_wgs)
     if args.max_launch_blocks >= 0:
         ctx.set_option("max_launch_blocks", args.max_launch_blocks)
+    for kv in args.option:
+        key, _, value = kv.partition("=")
+        ctx.set_option(key, int(value))
     # The cohort is not rewritten between steps: the kernel-internal layout is
     # converted by the first call and reused by the others (--convert-every-step
     # restores one conversion per step; it is reported either way).
@@ -900,10 +1068,11 @@ def main():
     extras = args.extra_configs
     if extras is None:
         if config == "c2" and not custom:
-            extras = "c1,c3,c4" if (use_dist and world >= 4) else "c1,c3"
+            extras = "c1,c3,c4" if (use_dist and world >= 4) else "c1,c3" if use_dist else "c0,c1,c3"
         else:
             extras = "none"
-    extra_keys = [k for k in extras.split(",") if k and k != "none"]
+    extra_keys_c0 = [k for k in extras.split(",") if k == "c0"]
+    extra_keys = [k for k in extras.split(",") if k and k not in ("none", "c0")]
     # (steps, warm-up) of the configurations carried beside the headline
     extra_plan = {"c1": (20, 2), "c2": (4, 1), "c3": (2, 1), "c4": (1, 1)}
 
@@ -992,6 +1161,8 @@ def main():
             }
             del e
             torch.cuda.empty_cache()
+        if "c0" in extra_keys_c0:
+            others["c0"] = real_input_path(args, ctx, local_rank)
         if others:
             out["other_configs"] = others
         print(json.dumps(out), file=json_out, flush=True)

@@ -112,10 +112,19 @@ struct cuking_ctx {
   // Filter variant (king_filter.hip): control words, candidate list and dense-
   // quadrant list, one set per stream like the split scratch.  The two caps are
   // options so that tests can force the dense and the list-full paths.
-  std::vector<std::pair<hipStream_t, uint8_t *>> filter_scratch;
+  struct FilterScratch {
+    hipStream_t stream;
+    uint8_t *base;
+    uint64_t tiles;  // the block size (tiles of its enumeration) the lists are sized for
+  };
+  std::vector<FilterScratch> filter_scratch;
   uint32_t filter_quadrant_cap = kFilterQuadrantCap;
   uint32_t filter_cand_cap = kFilterCandCap;
   uint32_t filter_split_min_steps = 8;  // k-steps per remainder piece, at least
+  // Check points of the filter kernel (king_common.h): check 0 (forecast) 0 off, 1 for
+  // launches of fewer than 16 rounds, 2 always; check 1 (rigorous) 0 off, 1 the entry the
+  // kernel picks from threshold and cohort, 2 + k entry k of the share menu forced.
+  int filter_check0 = 1, filter_check1 = 1;
 
   // What the plane workspace holds: the block it was converted for and which
   // 64-sample plane tiles of it have been converted (cuking_compute_king_rect
@@ -300,11 +309,12 @@ cuking_status split_scratch_for(cuking_ctx *ctx, hipStream_t stream,
   return CUKING_OK;
 }
 
-// Filter scratch of `stream` (allocated on first use; the control words are
-// zeroed by every launch chunk), or nothing when the context's variant is not
-// the filter variant.  Fills the filter fields of `a`.
+// Filter scratch of `stream` for a block of `tiles` tiles (allocated on first use, again
+// when a larger block comes; the control words are zeroed by every launch chunk), or
+// nothing when the context's variant is not the filter variant.  Fills the filter
+// fields of `a`.
 cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const PlaneGeometry &geo,
-                                 TiledArgs *a) {
+                                 uint64_t tiles, TiledArgs *a) {
   a->sample_stats = nullptr;
   a->t2 = nullptr;
   a->filter_ctrl = nullptr;
@@ -314,18 +324,35 @@ cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const Plan
   a->fsplit_parts = a->fsplit_first = a->fsplit_tile0 = 0;
   a->fsplit_slabs = nullptr;
   a->fsplit_tickets = nullptr;
+  a->wg_words = nullptr;
+  a->tile_done = nullptr;
+  a->prefix_u = nullptr;
+  a->cohort_sums = nullptr;
+  a->check_steps = nullptr;
+  a->check0 = a->check1 = 0;
   if (ctx->variant != kMfmaFilterVariant) return CUKING_OK;
-  uint8_t *base = nullptr;
+  const FilterScratchLayout want = filter_scratch_layout(tiles);
+  cuking_ctx::FilterScratch *entry = nullptr;
   for (auto &e : ctx->filter_scratch)
-    if (e.first == stream) base = e.second;
-  if (base == nullptr) {
-    if (ctx->filter_scratch.size() >= 8) {  // (see split_scratch_for)
+    if (e.stream == stream) entry = &e;
+  if (entry != nullptr && filter_scratch_layout(entry->tiles).bytes < want.bytes) {
+    // a larger block: kernels of this stream may still use the old lists
+    ++ctx->host_syncs;
+    HIP_TRY(hipStreamSynchronize(stream));
+    (void)hipFree(entry->base);
+    entry->base = nullptr;
+  }
+  if (entry == nullptr || entry->base == nullptr) {
+    if (entry == nullptr && ctx->filter_scratch.size() >= 8) {
+      // Streams come and go (torch hands out new handles): the oldest entry makes room.
       ++ctx->host_syncs;
-      HIP_TRY(hipDeviceSynchronize());
-      for (auto &e : ctx->filter_scratch) (void)hipFree(e.second);
-      ctx->filter_scratch.clear();
+      HIP_TRY(hipStreamSynchronize(ctx->filter_scratch.front().stream));
+      (void)hipGetLastError();  // (a stream its owner has destroyed meanwhile: nothing runs on it)
+      (void)hipFree(ctx->filter_scratch.front().base);
+      ctx->filter_scratch.erase(ctx->filter_scratch.begin());
     }
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base), filter_scratch_bytes()));
+    uint8_t *base = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&base), want.bytes));
     ++ctx->workspace_allocations;
     // (the running totals behind "filter_candidates" / "filter_dense_quadrants")
     // ... and the tickets of the remainder pieces, zero between launches
@@ -334,22 +361,35 @@ cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const Plan
       (void)hipFree(base);
       HIP_TRY(e);
     }
-    ctx->filter_scratch.emplace_back(stream, base);
+    if (entry == nullptr) {
+      ctx->filter_scratch.push_back({stream, base, tiles});
+      entry = &ctx->filter_scratch.back();
+    } else {
+      entry->base = base;
+      entry->tiles = tiles;
+    }
   }
+  uint8_t *base = entry->base;
+  const FilterScratchLayout l = filter_scratch_layout(entry->tiles);
   a->sample_stats = plane_stats(ctx->planes, geo);
   a->t2 = plane_t2(ctx->planes, geo);
+  a->prefix_u = plane_prefix_u(ctx->planes, geo);
+  a->cohort_sums = plane_cohort_sums(ctx->planes, geo);
   a->filter_ctrl = reinterpret_cast<uint32_t *>(base);
-  a->fsplit_tickets = reinterpret_cast<uint32_t *>(base + kFilterCtrlBytes);
-  a->cand_list = reinterpret_cast<uint2 *>(base + kFilterCtrlBytes + kFilterTicketBytes);
-  a->cand_cap = ctx->filter_cand_cap;
+  a->fsplit_tickets = reinterpret_cast<uint32_t *>(base + l.tickets);
+  a->wg_words = reinterpret_cast<uint32_t *>(base + l.wg_words);
+  a->tile_done = base + l.tile_done;
+  a->cand_list = reinterpret_cast<uint2 *>(base + l.cand);
+  a->cand_cap = ctx->filter_cand_cap < l.cand_entries ? ctx->filter_cand_cap : l.cand_entries;
   a->quadrant_cap = ctx->filter_quadrant_cap;
-  a->dense_list = a->cand_list + kFilterCandCap;
-  a->dense_cap = kFilterChunkTiles * 4;
+  a->dense_list = reinterpret_cast<uint2 *>(base + l.dense);
+  a->dense_cap = l.chunk_tiles * 4;
   // (remainder splitting follows the matrix-core kernels' switch: "split_wgs" 0 = never)
   a->fsplit_first = ctx->filter_split_min_steps;  // (on entry: launch_filter)
-  a->fsplit_slabs = ctx->split_wgs != 0
-                        ? reinterpret_cast<float4 *>(a->dense_list + (size_t)kFilterChunkTiles * 4)
-                        : nullptr;
+  a->fsplit_slabs = ctx->split_wgs != 0 ? reinterpret_cast<float4 *>(base + l.slabs) : nullptr;
+  a->check0 = (uint32_t)ctx->filter_check0;  // (switches on entry: launch_filter)
+  a->check1 = (uint32_t)ctx->filter_check1;
+  a->check_steps = plane_check_steps(ctx->planes, geo);
   return CUKING_OK;
 }
 
@@ -578,7 +618,7 @@ cuking_status run_tiled(cuking_ctx *ctx, const cuking_submatrix &sm,
                 (unsigned long long)n_tiles);
   if (tile_begin == tile_end) return CUKING_OK;
 
-  TiledArgs a;
+  TiledArgs a = {};
   a.planes = ctx->planes;
   a.geo = geo;
   a.tiles = tiles;
@@ -605,7 +645,7 @@ cuking_status run_tiled(cuking_ctx *ctx, const cuking_submatrix &sm,
   a.dyn_wgs = 0;
   st = split_scratch_for(ctx, stream, &a.split_scratch, &a.split_counters);
   if (st != CUKING_OK) return st;
-  st = filter_scratch_for(ctx, stream, geo, &a);
+  st = filter_scratch_for(ctx, stream, geo, n_tiles, &a);
   if (st != CUKING_OK) return st;
 
   EventPair *ev = nullptr;
@@ -694,7 +734,7 @@ void cuking_ctx_destroy(cuking_ctx *ctx) {
   if (ctx->planes) (void)hipFree(ctx->planes);
   if (ctx->band_prefix) (void)hipFree(ctx->band_prefix);
   for (auto &e : ctx->split_scratch) (void)hipFree(e.second);
-  for (auto &e : ctx->filter_scratch) (void)hipFree(e.second);
+  for (auto &e : ctx->filter_scratch) (void)hipFree(e.base);
   for (auto &r : ctx->readers)
     if (r.second) (void)hipEventDestroy(r.second);
   ctx->king_timer.destroy();
@@ -772,6 +812,26 @@ cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
     if (value < 1 || value > 4096)
       return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "filter_split_min_steps outside [1, 4096]");
     ctx->filter_split_min_steps = (uint32_t)value;
+    return CUKING_OK;
+  }
+  if (strcmp(key, "filter_check_min_steps") == 0) {  // test hook, process-wide: checks for short bitsets
+    if (value < 4 || value > 1 << 20)
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "filter_check_min_steps outside [4, 2^20]");
+    set_filter_check_min_steps((uint32_t)value);
+    ctx->prepared.valid = false;  // (prefix counts of the workspace belong to the old value)
+    return CUKING_OK;
+  }
+  if (strcmp(key, "filter_check0") == 0) {  // forecast check: 0 off, 1 short launches, 2 always
+    if (value < 0 || value > 2)
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "filter_check0 outside [0, 2]");
+    ctx->filter_check0 = (int)value;
+    return CUKING_OK;
+  }
+  if (strcmp(key, "filter_check1") == 0) {  // rigorous check: 0 off, 1 automatic, 2 + k entry k
+    if (value < 0 || value > 1 + (int64_t)kNumCheckShares || value == 2)
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "filter_check1 outside {0, 1, 3 .. %u}",
+                  1 + kNumCheckShares);
+    ctx->filter_check1 = (int)value;
     return CUKING_OK;
   }
   if (strcmp(key, "filter_cand_cap") == 0) {  // tests: a short candidate list
@@ -1007,17 +1067,22 @@ cuking_status cuking_ctx_get_option(const cuking_ctx *ctx, const char *key,
   else if (strcmp(key, "filter_quadrant_cap") == 0) *value = ctx->filter_quadrant_cap;
   else if (strcmp(key, "filter_cand_cap") == 0) *value = ctx->filter_cand_cap;
   else if (strcmp(key, "filter_split_min_steps") == 0) *value = ctx->filter_split_min_steps;
-  else if (strcmp(key, "filter_candidates") == 0 || strcmp(key, "filter_dense_quadrants") == 0) {
-    // Diagnostics (they WAIT for the device): pairs the bound let through and
-    // quadrants handed to the exact kernel, summed over the context's streams,
-    // since the scratch was allocated.
-    const size_t word = strcmp(key, "filter_candidates") == 0 ? 2 : 3;  // (u64 words)
+  else if (strcmp(key, "filter_check0") == 0) *value = ctx->filter_check0;
+  else if (strcmp(key, "filter_check1") == 0) *value = ctx->filter_check1;
+  else if (strcmp(key, "filter_candidates") == 0 || strcmp(key, "filter_dense_quadrants") == 0 ||
+           strcmp(key, "filter_early_exits") == 0) {
+    // Diagnostics (they WAIT for the device): pairs the bound let through, quadrants
+    // handed to the exact kernel, and tiles that left at the rigorous check point, summed
+    // over the context's streams, since the scratch was allocated.
+    const size_t word = strcmp(key, "filter_candidates") == 0        ? kCtrlTotalCand
+                        : strcmp(key, "filter_dense_quadrants") == 0 ? kCtrlTotalDense
+                                                                     : kCtrlTotalEarly;
     unsigned long long total = 0;
     if (hipSetDevice(ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
       return cuking_fail(CUKING_ERR_DEVICE, "device wait failed");
     for (auto &e : ctx->filter_scratch) {
       unsigned long long v = 0;
-      if (hipMemcpy(&v, e.second + word * 8, 8, hipMemcpyDeviceToHost) != hipSuccess)
+      if (hipMemcpy(&v, e.base + word * 4, 8, hipMemcpyDeviceToHost) != hipSuccess)
         return cuking_fail(CUKING_ERR_DEVICE, "reading the filter counters failed");
       total += v;
     }
@@ -1196,7 +1261,7 @@ cuking_status cuking_compute_king_rect(
                     sm->i_begin + c * v.tile);
   }
 
-  TiledArgs a;
+  TiledArgs a = {};
   a.planes = ctx->planes;
   a.geo = geo;
   a.tiles = tiles;
@@ -1226,7 +1291,7 @@ cuking_status cuking_compute_king_rect(
   a.dyn_wgs = 0;
   st = split_scratch_for(ctx, (hipStream_t)stream, &a.split_scratch, &a.split_counters);
   if (st != CUKING_OK) return st;
-  st = filter_scratch_for(ctx, (hipStream_t)stream, geo, &a);
+  st = filter_scratch_for(ctx, (hipStream_t)stream, geo, total_tiles(make_tiles(geo, v, ctx->band_rows)), &a);
   if (st != CUKING_OK) return st;
   EventPair *ev = nullptr;
   if (ctx->timing) HIP_TRY(ctx->king_timer.begin((hipStream_t)stream, &ev));
@@ -1287,25 +1352,34 @@ cuking_status cuking_ctx_reserve(cuking_ctx *ctx, const cuking_submatrix *sm,
     }
   }
   if (ctx->variant == kMfmaFilterVariant) {
+    // (the scratch cache holds 8 streams and evicts the oldest for a ninth: make room
+    //  now, so that nothing reserved here is the one evicted)
     size_t missing = 0;
     for (size_t k = 0; k < num_streams; ++k) {
       bool have = false;
-      for (auto &e : ctx->filter_scratch) have = have || e.first == (hipStream_t)streams[k];
+      for (auto &e : ctx->filter_scratch) have = have || e.stream == (hipStream_t)streams[k];
       missing += have ? 0 : 1;
     }
     if (missing != 0 && ctx->filter_scratch.size() + missing > 8) {
+      // drop what this reservation does not name
       ++ctx->host_syncs;
       HIP_TRY(hipDeviceSynchronize());
-      for (auto &e : ctx->filter_scratch) (void)hipFree(e.second);
-      ctx->filter_scratch.clear();
+      std::vector<cuking_ctx::FilterScratch> keep;
+      for (auto &e : ctx->filter_scratch) {
+        bool named = false;
+        for (size_t k = 0; k < num_streams; ++k) named = named || e.stream == (hipStream_t)streams[k];
+        if (named) keep.push_back(e);
+        else (void)hipFree(e.base);
+      }
+      ctx->filter_scratch.swap(keep);
     }
   }
   for (size_t k = 0; k < num_streams; ++k) {
     uint32_t *scratch, *counters;
     st = split_scratch_for(ctx, (hipStream_t)streams[k], &scratch, &counters);
     if (st != CUKING_OK) return st;
-    TiledArgs unused;
-    st = filter_scratch_for(ctx, (hipStream_t)streams[k], geo, &unused);
+    TiledArgs unused = {};
+    st = filter_scratch_for(ctx, (hipStream_t)streams[k], geo, total_tiles(tiles), &unused);
     if (st != CUKING_OK) return st;
   }
   return CUKING_OK;

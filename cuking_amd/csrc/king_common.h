@@ -204,8 +204,57 @@ struct TiledArgs {
   uint32_t fsplit_parts, fsplit_first, fsplit_tile0;
   float4 *fsplit_slabs;
   uint32_t *fsplit_tickets;
+  // Filter kernel, check points inside the k loop (king_filter.hip, "Check points"):
+  // after a number of k-steps (even) the workgroup tests its 256 x 256 sums against the
+  // bound evaluated on the sites so far -- per-sample counts over that prefix, one
+  // float per plane sample.  Check 1 is rigorous (every term of X is non-negative): a
+  // tile none of whose pairs can still become a candidate leaves there.  Check 0
+  // is a forecast (the bound scaled to the prefix) for short launches: a tile most
+  // of whose quadrants look dense leaves for the exact kernel at once.  One word
+  // per tile of the launch chunk (wg_words, zero at launch) carries the wavefronts'
+  // findings to one another; tile_done[t] = 1 tells the fallback launch that tile
+  // t of the chunk needs nothing more.
+  // check_steps[k] (device memory, written by the kernel that computed the prefix counts:
+  // the two always agree): k-steps behind share k of kCheckShares64 (0 = bitset too short
+  // for checks); prefix_u[k * s_stride + s]: u of plane sample s over those k-steps' sites.
+  // Entry 0 is the forecast's (used when check0 != 0: short launches), entries 1 .. the
+  // rigorous check's: every workgroup picks the same one from the threshold and the
+  // cohort's mean missing and het rates (cohort_sums: samples, missing calls, het calls).
+  const uint32_t *check_steps;
+  const float *prefix_u;
+  const unsigned long long *cohort_sums;
+  uint32_t check0, check1;  // switches (check1: 0 off, 1 automatic, 2 + k: entry k forced)
+  uint32_t *wg_words;
+  uint8_t *tile_done;
+  // Persistent mode of the four-product kernel (king_mfma.hip), the filter's
+  // fallback: when *gate != 0, workgroup b of a fixed grid takes units b, b + grid,
+  // ... of the gate_count units from tile_begin on (same order as a whole-tile
+  // launch: 32 consecutive units per XCD and round), skipping the quadrants of
+  // tiles with skip_tiles[tile - skip_base] != 0; when *gate == 0 every workgroup
+  // leaves at once.  gate == nullptr: not this mode.
+  const uint32_t *gate;
+  uint32_t gate_count;
+  const uint8_t *skip_tiles;
+  uint64_t skip_base;
 };
 
+// Prefix statistics: the k-steps (of 256 sites) a check may sit behind, as shares of the
+// bitset in 1/64ths -- the per-sample prefix counts are computed for every entry when
+// the layout is prepared, a launch picks the entries its threshold calls for.
+constexpr uint32_t kNumCheckShares = 8;
+constexpr uint32_t kCheckShares64[kNumCheckShares] = {8, 50, 53, 56, 58, 60, 61, 62};
+// k-steps (of 256 sites) behind share k for a bitset of `all_steps` k-steps: even (the
+// k loop runs two k-steps per trip), 0 when the bitset is too short for a check to pay.
+__host__ __device__ inline uint32_t check_step_of(uint32_t all_steps, uint32_t k,
+                                                  uint32_t min_steps = 64) {
+  if (all_steps < min_steps) return 0;
+  return (uint32_t)((uint64_t)all_steps * kCheckShares64[k] / 64) & ~1u;
+}
+// Remainder splitting: at most this many pieces per launch (one per CU), a slab of
+// 256 x 256 float sums and a ticket word each.
+constexpr uint32_t kFilterSplitSlabs = 256;
+constexpr size_t kFilterSlabBytes = 256 * 256 * sizeof(float);
+constexpr size_t kFilterTicketBytes = kFilterSplitSlabs * sizeof(uint32_t);
 // Bytes of the plane workspace for a geometry.
 __host__ __device__ inline size_t plane_bytes(const PlaneGeometry &g,
                                               uint32_t layout) {
@@ -214,7 +263,8 @@ __host__ __device__ inline size_t plane_bytes(const PlaneGeometry &g,
   const size_t base = (size_t)g.k_words * g.s_stride * (layout == kLayoutQuad ? 8 : 16);
   if (layout == kLayoutNibble) return base + base / 4;  // + the het-only copy
   if (layout == kLayoutNibbleStats)
-    return base + base / 4 + base / 2 + (size_t)g.s_stride * sizeof(float2);
+    return base + base / 4 + base / 2 + (size_t)g.s_stride * sizeof(float2) +
+           (size_t)g.s_stride * kNumCheckShares * sizeof(float) + 64 + 64;
   return base;
 }
 // Where the T2 layout and the per-sample statistics of kLayoutNibbleStats start
@@ -224,6 +274,18 @@ __host__ __device__ inline const uint4 *plane_t2(const uint4 *planes, const Plan
 }
 __host__ __device__ inline const float2 *plane_stats(const uint4 *planes, const PlaneGeometry &g) {
   return reinterpret_cast<const float2 *>(planes + (size_t)g.k_words * g.s_stride * 7 / 4);
+}
+// ... behind them the prefix counts (kNumCheckShares x s_stride floats) and the cohort's
+// sums (three u64: samples counted, missing calls, het calls; s_stride is a multiple of
+// the tile edge, so everything stays 16-byte aligned), then the k-steps behind each share
+// as the prefix counts were computed for (kNumCheckShares u32).
+__host__ __device__ inline const float *plane_prefix_u(const uint4 *planes, const PlaneGeometry &g) {
+  return reinterpret_cast<const float *>(plane_stats(planes, g) + g.s_stride);
+}
+__host__ __device__ inline const unsigned long long *plane_cohort_sums(const uint4 *planes,
+                                                                       const PlaneGeometry &g) {
+  return reinterpret_cast<const unsigned long long *>(plane_prefix_u(planes, g) +
+                                                      (size_t)g.s_stride * kNumCheckShares);
 }
 
 // One compiled shape of the tiled kernel.
@@ -275,14 +337,44 @@ constexpr uint32_t kFilterCandCap = 1u << 25;
 // profiles/r03_filter_curve.txt).
 constexpr uint32_t kFilterQuadrantCap = 384;
 constexpr size_t kFilterCtrlBytes = 256;
-// Remainder splitting: at most this many pieces per launch (one per CU), a slab of
-// 256 x 256 float sums and a ticket word each.
-constexpr uint32_t kFilterSplitSlabs = 256;
-constexpr size_t kFilterSlabBytes = 256 * 256 * sizeof(float);
-constexpr size_t kFilterTicketBytes = kFilterSplitSlabs * sizeof(uint32_t);
-inline size_t filter_scratch_bytes() {
-  return kFilterCtrlBytes + kFilterTicketBytes + (size_t)kFilterCandCap * sizeof(uint2) +
-         (size_t)kFilterChunkTiles * 4 * sizeof(uint2) + kFilterSplitSlabs * kFilterSlabBytes;
+// Control words (uint32 indices into filter_ctrl).  Zeroed in front of every launch
+// chunk (kCtrlChunkBytes): 0 candidates of the chunk, 1 dense quadrants of the chunk
+// (list slots), 2 dynamic-tail counter, 3 quadrants finished, 4 quadrants of tiles that
+// left for the exact kernel at check 0, 5 "every remaining tile leaves" (most quadrants
+// so far went dense), 6 gate of the fallback launch (some tile left).  Running totals
+// since the scratch was allocated (u64 each): 16 candidates, 18 quadrants handed to the
+// exact kernel, 20 tiles that left at the rigorous check.
+constexpr uint32_t kCtrlCand = 0, kCtrlDense = 1, kCtrlDyn = 2, kCtrlFinished = 3,
+                   kCtrlLeft = 4, kCtrlAllLeave = 5, kCtrlGate = 6;
+constexpr size_t kCtrlChunkBytes = 32;
+constexpr uint32_t kCtrlTotalCand = 16, kCtrlTotalDense = 18, kCtrlTotalEarly = 20;
+__host__ __device__ inline const uint32_t *plane_check_steps(const uint4 *planes,
+                                                             const PlaneGeometry &g) {
+  return reinterpret_cast<const uint32_t *>(plane_cohort_sums(planes, g) + 8);
+}
+
+// Scratch of one stream: control words, tickets, one word and one flag per tile of a
+// launch chunk, the candidate list, the dense-quadrant list, the remainder slabs.  The
+// lists are sized for the block the scratch serves (`tiles` 256-sample tiles in its
+// enumeration): 64 candidates per quadrant of a chunk, at most kFilterCandCap.
+struct FilterScratchLayout {
+  size_t tickets, wg_words, tile_done, cand, dense, slabs, bytes;
+  uint32_t chunk_tiles, cand_entries;
+};
+inline FilterScratchLayout filter_scratch_layout(uint64_t tiles) {
+  FilterScratchLayout l;
+  l.chunk_tiles = (uint32_t)(tiles < kFilterChunkTiles ? (tiles ? tiles : 1) : kFilterChunkTiles);
+  const uint64_t cand = (uint64_t)l.chunk_tiles * 4 * 64;
+  l.cand_entries = (uint32_t)(cand < kFilterCandCap ? cand : kFilterCandCap);
+  auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+  l.tickets = kFilterCtrlBytes;
+  l.wg_words = l.tickets + kFilterTicketBytes;
+  l.tile_done = l.wg_words + up((size_t)l.chunk_tiles * sizeof(uint32_t));
+  l.cand = l.tile_done + up(l.chunk_tiles);
+  l.dense = l.cand + up((size_t)l.cand_entries * sizeof(uint2));
+  l.slabs = l.dense + up((size_t)l.chunk_tiles * 4 * sizeof(uint2));
+  l.bytes = l.slabs + kFilterSplitSlabs * kFilterSlabBytes;
+  return l;
 }
 inline bool is_mfma_variant(int v) {
   return v == kMfmaVariant || v == kMfmaN4Variant || v == kMfmaFilterVariant;
@@ -307,6 +399,10 @@ hipError_t launch_mfma(bool full, bool nibble, const TiledArgs &args, uint64_t n
                        uint32_t lds_bytes, hipStream_t stream);
 // The four-product kernel, lean form, over args.tile_list with `grid` workgroups.
 hipError_t launch_mfma_list(const TiledArgs &args, uint32_t grid, hipStream_t stream);
+// The four-product kernel, lean form, persistent mode (TiledArgs::gate): `grid`
+// workgroups walk num_units units from args.tile_begin on, if the gate is open.
+hipError_t launch_mfma_gated(const TiledArgs &args, uint64_t num_units, uint32_t grid,
+                             hipStream_t stream);
 // The filter variant (king_filter.hip): num_tiles 256-sample tiles from
 // args.tile_begin; needs args.filter_ctrl etc. (king_abi.hip: filter scratch).
 hipError_t launch_filter(const TiledArgs &args, uint64_t num_tiles, hipStream_t stream);
@@ -314,6 +410,8 @@ hipError_t launch_filter(const TiledArgs &args, uint64_t num_tiles, hipStream_t 
 hipError_t launch_sample_stats(const uint64_t *d_bit_sets, uint32_t words_per_sample,
                                const PlaneGeometry &geo, uint4 *d_planes, uint32_t s_begin,
                                uint32_t s_end, hipStream_t stream);
+// Test hook, process-wide: bitsets of fewer k-steps get no check points (default 64).
+void set_filter_check_min_steps(uint32_t steps);
 // Bytes of split scratch (counters, then slabs) for `wgs` workgroups, and of
 // the counter part alone (the only part that must start out zero).
 size_t mfma_split_scratch_bytes(uint32_t wgs);

@@ -110,6 +110,8 @@ __device__ __forceinline__ bool decode_tile(const TiledArgs &a, uint64_t t,
   }
   if (a.quad == 0) return decode_tile_space(a, t, tr, tc);
   // Quadrant mode: quadrant t % 4 of the 256-sample tile t / 4.
+  // (the filter's fallback launch: tiles the filter kernel has dealt with)
+  if (a.skip_tiles != nullptr && a.skip_tiles[(t >> 2) - a.skip_base] != 0) return false;
   uint32_t r, c;
   if (!decode_tile_space(a, t >> 2, &r, &c)) return false;
   *tr = 2 * r + (uint32_t)((t >> 1) & 1);

@@ -44,6 +44,8 @@
 // measurements; profiles/r03_ablation.txt and r03_filter_curve.txt the raw numbers.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+
+#include <atomic>
 #include <stdlib.h>
 
 #include "king_common.h"
@@ -89,45 +91,81 @@ __device__ __forceinline__ uint32_t source_sample(const PlaneGeometry &geo, uint
 
 // One wavefront per plane sample: (|Y| - |M|, |H|) as floats (exact below 2^24
 // sites).  Padding sites of the last word are missing (cuking.cu:513-523) and
-// count as such; padding samples get (0, 0).
+// count as such; padding samples get (0, 0).  Beside them the same |Y| - |M| over
+// the site prefixes the kernel's check points may sit behind (prefix[k][sample]:
+// the first 256 check_steps[k] sites = 4 check_steps[k] words of 64), and the
+// cohort's sums (samples, missing calls, het calls) the kernel picks a check from.
+struct CheckWords {
+  uint32_t w[kNumCheckShares];  // 64-bit words behind each share (0: no such check)
+};
 __global__ __launch_bounds__(256) void sample_stats_kernel(
     const uint64_t *__restrict__ bits, uint32_t words_per_sample, PlaneGeometry geo,
-    float2 *__restrict__ stats, uint32_t s_begin, uint32_t s_end) {
+    float2 *__restrict__ stats, float *__restrict__ prefix, unsigned long long *__restrict__ sums,
+    uint32_t *__restrict__ steps_out, CheckWords cw, uint32_t s_begin, uint32_t s_end) {
   const uint32_t lane = threadIdx.x & 63;
+  if (blockIdx.x == 0 && threadIdx.x < kNumCheckShares) steps_out[threadIdx.x] = cw.w[threadIdx.x] / 4;
   const uint32_t ps = s_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ps >= s_end) return;  // whole wavefront
   const uint32_t src = source_sample(geo, ps);
   int32_t yc = 0, mc = 0, hc = 0;
+  int32_t pc[kNumCheckShares] = {};
   if (src != kNoPair) {
     const uint32_t n = words_per_sample / 2;
     const uint64_t *het = bits + (uint64_t)src * words_per_sample;
     const uint64_t *hom = het + n;
     constexpr uint32_t kAhead = 4;  // words per lane and plane requested before any is counted
-    for (uint32_t w0 = 0; w0 < n; w0 += 64 * kAhead) {
-      uint64_t h[kAhead], v[kAhead];
+    // The words in the order of the share menu's boundaries (ascending): segment c ends
+    // where share c does, and the running |Y| - |M| at its end is that prefix's count --
+    // no per-word comparison against eight boundaries.
+    uint32_t seg_begin = 0;
 #pragma unroll
-      for (uint32_t k = 0; k < kAhead; ++k) {
-        const uint32_t w = w0 + 64 * k + lane;
-        const bool in = w < n;
-        h[k] = in ? het[w] : 0ull;
-        v[k] = in ? hom[w] : 0ull;
-      }
+    for (uint32_t c = 0; c <= kNumCheckShares; ++c) {
+      uint32_t seg_end = c < kNumCheckShares ? cw.w[c] : n;
+      if (seg_end > n) seg_end = n;
+      if (seg_end < seg_begin) seg_end = seg_begin;  // (a share without a check: 0 words)
+      for (uint32_t w0 = seg_begin; w0 < seg_end; w0 += 64 * kAhead) {
+        uint64_t h[kAhead], v[kAhead];
 #pragma unroll
-      for (uint32_t k = 0; k < kAhead; ++k) {
-        const bool in = w0 + 64 * k + lane < n;  // beyond the plane: contributes nothing
-        yc += in ? __popcll(~h[k]) : 0;  // homozygous and defined (missing has the het bit set)
-        mc += __popcll(h[k] & v[k]);     // missing
-        hc += __popcll(h[k] & ~v[k]);    // het
+        for (uint32_t k = 0; k < kAhead; ++k) {
+          const uint32_t w = w0 + 64 * k + lane;
+          const bool in = w < seg_end;
+          h[k] = in ? het[w] : 0ull;
+          v[k] = in ? hom[w] : 0ull;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kAhead; ++k) {
+          const bool in = w0 + 64 * k + lane < seg_end;  // beyond the segment: contributes nothing
+          yc += in ? __popcll(~h[k]) : 0;  // homozygous and defined (missing has the het bit set)
+          mc += __popcll(h[k] & v[k]);     // missing
+          hc += __popcll(h[k] & ~v[k]);    // het
+        }
       }
+      if (c < kNumCheckShares) pc[c] = yc - mc;  // (this lane's share; summed over the lanes below)
+      seg_begin = seg_end;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       yc += __shfl_xor(yc, off);
       mc += __shfl_xor(mc, off);
       hc += __shfl_xor(hc, off);
+#pragma unroll
+      for (uint32_t c = 0; c < kNumCheckShares; ++c) pc[c] += __shfl_xor(pc[c], off);
     }
   }
-  if (lane == 0) stats[ps] = make_float2((float)(yc - mc), (float)hc);
+  if (lane == 0) {
+    stats[ps] = make_float2((float)(yc - mc), (float)hc);
+#pragma unroll
+    for (uint32_t c = 0; c < kNumCheckShares; ++c) prefix[(size_t)c * geo.s_stride + ps] = (float)pc[c];
+    // (the cohort's sums feed a choice, not a result: a sample of the samples will do --
+    //  three device-scope atomics on three addresses for EVERY sample cost 3 ms at 100k)
+    if (src != kNoPair && ((blockIdx.x & 15) == 0 || gridDim.x < 64)) {
+      __hip_atomic_fetch_add(sums, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(sums + 1, (unsigned long long)mc, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(sums + 2, (unsigned long long)hc, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 __device__ __forceinline__ v16f mma(const v8i a, const v8i b, const v16f c) {
@@ -186,7 +224,7 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
     // counter is filter_ctrl[2], zeroed in front of every launch.)
     uint32_t *slot = reinterpret_cast<uint32_t *>(lds);
     if (threadIdx.x == 0)
-      *slot = __hip_atomic_fetch_add(a.filter_ctrl + 2, 1u, __ATOMIC_RELAXED,
+      *slot = __hip_atomic_fetch_add(a.filter_ctrl + kCtrlDyn, 1u, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const uint32_t t = __builtin_amdgcn_readfirstlane(*slot);
@@ -210,39 +248,43 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   const uint32_t wy = wave >> 1, wx = wave & 1;  // the wavefront's quadrant
   // When the bound does not thin this cohort out (a threshold inside the noise of
   // unrelated pairs, heavy missingness) nearly every quadrant ends on the dense list
-  // anyway: once most of at least 512 finished quadrants of the launch have, the
-  // remaining tiles skip the product and hand their quadrants over directly, so the
-  // worst case costs the exact kernel's time plus the first round of this one
-  // (filter_ctrl[1] dense quadrants, [3] quadrants finished; both per launch).
+  // anyway: once most of at least 512 finished quadrants of the launch have (or their
+  // tiles have left at check 0, below), every remaining tile leaves at once -- it
+  // touches nothing, and the fallback launch behind this one (the four-product kernel
+  // over the chunk in its own order, king_mfma.hip persistent mode) computes every tile
+  // that has not set its tile_done flag.  The worst case costs the exact kernel's time
+  // plus the first round of this one (short launches: plus an eighth of it, check 0).
 #ifndef CUKING_FILTER_GIVE_UP
 #define CUKING_FILTER_GIVE_UP 1  // (A/B: 0 = tiles never give up)
 #endif
-  if (CUKING_FILTER_GIVE_UP && !split) {
+  if (CUKING_FILTER_GIVE_UP && !split && a.tile_done != nullptr) {
     // ONE decision per workgroup (the counters move while the wavefronts read them,
     // and a wavefront that left alone would take its quarter of every stage's
     // requests with it): thread 0 reads, the stage memory carries the verdict.
     uint32_t *verdict = reinterpret_cast<uint32_t *>(lds);
     if (threadIdx.x == 0) {
-      const uint32_t dense_so_far = __hip_atomic_load(a.filter_ctrl + 1, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t finished = __hip_atomic_load(a.filter_ctrl + 3, __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_AGENT);
-      *verdict = (finished >= 512 && 2 * dense_so_far > finished) ? 1u : 0u;
+      uint32_t leave = __hip_atomic_load(a.filter_ctrl + kCtrlAllLeave, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+      if (leave == 0) {
+        const uint32_t dense_so_far =
+            __hip_atomic_load(a.filter_ctrl + kCtrlDense, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+            __hip_atomic_load(a.filter_ctrl + kCtrlLeft, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t finished = __hip_atomic_load(a.filter_ctrl + kCtrlFinished, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+        if (finished >= 512 && 2 * dense_so_far > finished) {
+          leave = 1;
+          __hip_atomic_store(a.filter_ctrl + kCtrlAllLeave, 1u, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(a.filter_ctrl + kCtrlGate, 1u, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      *verdict = leave;
     }
     __syncthreads();
     const bool give_up = *verdict != 0;
     __syncthreads();  // the word is stage memory from here on
-    if (give_up) {  // uniform across the workgroup
-      if (lane == 0 && !(a.tiles.diag && 2 * tc + wx < 2 * tr + wy)) {
-        const uint32_t slot = __hip_atomic_fetch_add(a.filter_ctrl + 1, 1u, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT);
-        if (slot < a.dense_cap) a.dense_list[slot] = make_uint2(2 * tr + wy, 2 * tc + wx);
-        __hip_atomic_fetch_add(a.filter_ctrl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.filter_ctrl + 6), 1ull,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      return;
-    }
+    if (give_up) return;  // uniform across the workgroup; tile_done stays 0
   }
   const uint32_t g = lane >> 5;                  // k-half of the MFMA operand
   const uint32_t lr = lane & 31;                 // row / column inside a block
@@ -274,18 +316,23 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   const uint32_t l_wave = (uint32_t)(uintptr_t)(lds_void_ptr)(
       lds + ((dma_side * 2 + dma_h) * kUnits) * kSliceU4);
   struct Addr { const char *src; uint32_t dst; };  // of unit 0; unit 1: + row_bytes, + 4 KiB
+  const uint32_t kstep_bytes = 2 * kUnits * row_bytes;
+  // The pipeline runs over one SEGMENT of the piece's k-steps at a time (one segment,
+  // unless the tile has check points, below): `seg_src` is the wavefront's first request
+  // of the segment, `seg_steps` its k-steps.
+  const char *seg_src = g_wave;
+  uint32_t seg_steps = num_steps;
   auto addr_of = [&](uint32_t step, uint32_t buf) {
     Addr pa;
-    if (step >= num_steps) step = num_steps - 1;  // clamped repeats (see king_mfma.hip)
-    pa.src = g_wave + (uint64_t)step * 2 * kUnits * row_bytes;
+    if (step >= seg_steps) step = seg_steps - 1;  // clamped repeats (see king_mfma.hip)
+    pa.src = seg_src + (uint64_t)step * kstep_bytes;
     pa.dst = l_wave + buf * (kStageU4 * 16);
     asm volatile("" : "+s"(pa.src), "+s"(pa.dst));
     return pa;
   };
-  const uint32_t kstep_bytes = 2 * kUnits * row_bytes;
   auto addr_next = [&](const Addr &cur, uint32_t step, uint32_t buf) {
     Addr pa;
-    const uint32_t adv = step < num_steps ? kstep_bytes : 0u;
+    const uint32_t adv = step < seg_steps ? kstep_bytes : 0u;
     pa.src = cur.src + adv;
     pa.dst = l_wave + buf * (kStageU4 * 16);
     asm volatile("" : "+s"(pa.src), "+s"(pa.dst));
@@ -309,17 +356,6 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
     for (int bj = 0; bj < 4; ++bj)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[bi][bj][r] = 0.f;
-
-  // Stages 0 .. 3 requested, stage 0 landed.
-#pragma unroll
-  for (int st = 0; st < kStages - 1; ++st) {
-    const Addr p0 = addr_of(st, st);
-    F_ISSUE4(p0, 0)
-    if (kUnits == 2) F_ISSUE4(p0, 1)
-  }
-  if (CUKING_FILTER_ABLATE != 1 && CUKING_FILTER_ABLATE != 2)
-    __builtin_amdgcn_s_waitcnt(vmcnt_imm((kStages - 2) * kStageReqs));
-  __syncthreads();
 
   // This lane's operand words inside a stage (uint4 units).
   uint32_t row_off = ((0 * 2 + g) * kUnits) * kSliceU4 + wy * 128 + lr;
@@ -415,23 +451,11 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
     F_BUILD_B(NXT, 6) F_MMA(CUR, 3, 2) F_BAR                                   \
     F_BUILD_B(NXT, 7) F_MMA(CUR, 3, 3) F_BAR                                   \
   }
-
-  // unit 0 of stage 0, set B
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    F_READ(k, 0, 0)
-  }
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    F_BUILD_B(0, k)
-  }
-  uint32_t buf = 0;  // buffer of the k-step being multiplied
   // k-step s requests stage s + kStages - 1 into the buffer stage s - 1 left: every
   // wavefront finished reading it before the hand-over of k-step s - 1.  The
   // hand-over of k-step s (stage s + 1 must have landed) comes in its last slice:
   // in flight then may be the stages after s + 1 and the requests of the newest one
   // that the slices before the last have issued (kSyncVm: 2 x 8 + 6 = 22).
-  Addr pa = addr_of(kStages - 1, kStages - 1);
 #if CUKING_FILTER_FINE
 #define F_KSTEP                                                                \
   {                                                                            \
@@ -455,22 +479,157 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
     ++step;                                                                    \
   }
 #endif
-  uint32_t step = 0;
+
+  // --- Check points (king_common.h).  X = sum over the sites of (g_i - g_j)^2 has only
+  // non-negative terms, so its sum over a PREFIX of the sites is a lower bound of X, and
+  // so is this kernel's bound of that prefix sum, u'_i + u'_j - 2 q' (u' over the prefix,
+  // sample_stats_kernel).  A pair can only pass the threshold when X < t min(|H_i|, |H_j|) +
+  // margin (|H| over ALL sites: the epilogue's own test): a tile none of whose 65,536 pairs
+  // satisfies u'_i + u'_j - 2 q' < that bound at the check point holds no record, whatever
+  // the remaining sites say -- it leaves.  For unrelated samples that happens from a share
+  // (1 - 2 thr) / (1 - 2 kappa) of the sites on, kappa = the level of the bound for unrelated
+  // pairs (their mean m (1 + m / (2 h (1 - m))) at missing rate m and het rate h, plus 4.6
+  // standard deviations 1 / sqrt(sites): tools/bound_tiers.py, profiles/r04_bound_tiers.txt):
+  // 0.88 of the sites at the default threshold and 1 % missing calls.  Every workgroup picks
+  // the same entry of the share menu from the cohort's sums.  (Check 0 is a FORECAST for
+  // short launches: the same test with the bound scaled to an eighth of the sites, counted
+  // per quadrant; a tile whose quadrants mostly look dense leaves for the exact kernel
+  // there instead of at its end.)  The pipeline is DRAINED at a check point -- the segment
+  // before it ends like a tile (every request landed, no fragment built ahead), the one
+  // behind it starts like a tile -- so that the check has the LDS for its per-sample
+  // values and the register file for its sweep, and the k loop's registers are not live
+  // across it: ~8 us per check of a 500 us tile.
+  uint32_t chk0 = 0, chk1 = 0, entry1 = 0;
+  if (!CUKING_FILTER_FINE && !split && a.check_steps != nullptr && a.tile_done != nullptr) {
+    if (a.check0 != 0) chk0 = a.check_steps[0];
+    if (a.check1 >= 2) {
+      entry1 = a.check1 - 2;
+    } else if (a.check1 == 1) {
+      const float ns = (float)a.cohort_sums[0], nm = (float)a.cohort_sums[1],
+                  nh = (float)a.cohort_sums[2];
+      if (ns > 0.f && nh > 0.f) {
+        const float sites = 256.f * (float)all_steps;
+        const float m = nm / (ns * sites), h = nh / (ns * sites);
+        const float kappa =
+            m * (1.f + m / (2.f * h * (1.f - m))) + 4.6f * rsqrtf(sites) + 0.003f;
+        const float f64 = 64.f * (1.f - 2.f * a.kin_threshold) / (1.f - 2.f * kappa);
+        // (a check costs ~3 % of a tile -- the pipeline drained and refilled, the sweep:
+        //  entries that save less than 6 % of the k-steps are for tests only)
+#pragma unroll
+        for (uint32_t k = kNumCheckShares - 1; k >= 1; --k)
+          if ((float)kCheckShares64[k] >= f64 && kCheckShares64[k] <= 60) entry1 = k;
+      }
+    }
+    if (entry1 >= 1 && entry1 < kNumCheckShares) chk1 = a.check_steps[entry1];
+    if (chk0 >= num_steps) chk0 = 0;
+    if (chk1 >= num_steps || chk1 <= chk0) chk1 = 0;
+  }
+  chk0 = __builtin_amdgcn_readfirstlane(chk0);
+  chk1 = __builtin_amdgcn_readfirstlane(chk1);
+  entry1 = __builtin_amdgcn_readfirstlane(entry1);
+
+  uint32_t seg_first = 0;  // k-steps of the piece behind us
+  bool left = false, left_forecast = false;  // the tile left at a check point (uniform)
+#pragma nounroll
+  while (true) {
+    uint32_t seg_end = num_steps;
+    if (chk1 > seg_first) seg_end = chk1;
+    if (chk0 > seg_first) seg_end = chk0;
+    seg_end = __builtin_amdgcn_readfirstlane(seg_end);
+    seg_steps = seg_end - seg_first;
+    seg_src = g_wave + (uint64_t)seg_first * kstep_bytes;
+    asm volatile("" : "+s"(seg_src), "+s"(seg_steps));
+
+    // Stages 0 .. 3 of the segment requested, stage 0 landed.
+#pragma unroll
+    for (int st = 0; st < kStages - 1; ++st) {
+      const Addr p0 = addr_of(st, st);
+      F_ISSUE4(p0, 0)
+      if (kUnits == 2) F_ISSUE4(p0, 1)
+    }
+    if (CUKING_FILTER_ABLATE != 1 && CUKING_FILTER_ABLATE != 2)
+      __builtin_amdgcn_s_waitcnt(vmcnt_imm((kStages - 2) * kStageReqs));
+    __syncthreads();
+    // unit 0 of stage 0, set B
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      F_READ(k, 0, 0)
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      F_BUILD_B(0, k)
+    }
+    uint32_t buf = 0;  // buffer of the k-step being multiplied
+    Addr pa = addr_of(kStages - 1, kStages - 1);
+    uint32_t step = 0;
 #if CUKING_FILTER_FINE
-  while (step + 3 < num_steps) {
-    F_KSTEP
-    F_KSTEP
-    F_KSTEP
-    F_KSTEP
-  }
-  while (step < num_steps) F_KSTEP
+    while (step + 3 < seg_steps) {
+      F_KSTEP
+      F_KSTEP
+      F_KSTEP
+      F_KSTEP
+    }
+    while (step < seg_steps) F_KSTEP
 #else
-  while (step + 1 < num_steps) {
-    F_KSTEP
-    F_KSTEP
-  }
-  if (step < num_steps) F_KSTEP
+    while (step + 1 < seg_steps) {
+      F_KSTEP
+      F_KSTEP
+    }
+    if (step < seg_steps) F_KSTEP
 #endif
+    // The clamped repeats of the last stage must have landed before the stages
+    // become the check's or the epilogue's scratch.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    __syncthreads();
+    if (seg_end == num_steps) break;
+
+    // --- the check behind k-step seg_end of the tile
+    const bool forecast = seg_end == chk0;  // uniform
+    const float scale = forecast ? (float)kCheckShares64[0] * (1.f / 64.f) : 1.f;
+    float2 *const ck_rows = reinterpret_cast<float2 *>(lds);  // (u over the prefix, scaled bound)
+    float2 *const ck_cols = ck_rows + kT;
+    uint32_t *const ck_words = reinterpret_cast<uint32_t *>(ck_cols + kT);  // one per wavefront
+    {
+      const float *const pu = a.prefix_u + (size_t)(forecast ? 0u : entry1) * s_stride;
+      const float t = 2.f - 4.f * a.kin_threshold;
+      const size_t ir = (size_t)tr * kT + threadIdx.x;
+      const size_t ic = (size_t)a.geo.col_base + (size_t)tc * kT + threadIdx.x;
+      ck_rows[threadIdx.x] = make_float2(pu[ir], scale * fmaf(t, a.sample_stats[ir].y, 8.f));
+      ck_cols[threadIdx.x] = make_float2(pu[ic], scale * fmaf(t, a.sample_stats[ic].y, 8.f));
+    }
+    __syncthreads();
+    uint32_t cnt = 0;  // pairs of this lane still under the bound
+    {
+      float2 cc[4];
+#pragma unroll
+      for (int bj = 0; bj < 4; ++bj) cc[bj] = ck_cols[wx * 128 + bj * 32 + lr];
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float2 cr = ck_rows[wy * 128 + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * g];
+#pragma unroll
+          for (int bj = 0; bj < 4; ++bj)
+            cnt += fmaf(-0.5f, acc[bi][bj][r], cr.x + cc[bj].x) < fminf(cr.y, cc[bj].y) ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (lane == 0) ck_words[wave] = forecast ? (cnt > a.quadrant_cap ? 1u : 0u) : (cnt != 0 ? 1u : 0u);
+    __syncthreads();
+    uint32_t found = ck_words[0] + ck_words[1] + ck_words[2] + ck_words[3];
+    found = __builtin_amdgcn_readfirstlane(found);
+    __syncthreads();  // (the words are stage memory again from here on)
+    if (forecast ? found >= 3 : found == 0) {
+      // The tile leaves (uniform; nothing is in flight; the book-keeping follows behind
+      // the loop: a divergent branch on the way out makes the compiler treat the whole
+      // loop as divergent, request addresses and all).
+      left = true;
+      left_forecast = forecast;
+      break;
+    }
+    seg_first = seg_end;
+  }
 #undef F_KSTEP
 #undef F_SLICE_A
 #undef F_SLICE_B
@@ -482,11 +641,33 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
 #undef F_PINF
 #undef F_READ
 #undef F_ISSUE4
+  if (left) {
+    // Forecast: the tile leaves for the exact kernel -- its quadrants count as handed
+    // over, the fallback launch is needed.  Rigorous check: for good.
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(a.filter_ctrl + kCtrlFinished, 4u, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+      if (left_forecast) {
+        __hip_atomic_fetch_add(a.filter_ctrl + kCtrlLeft, 4u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.filter_ctrl + kCtrlGate, 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(
+            reinterpret_cast<unsigned long long *>(a.filter_ctrl + kCtrlTotalDense), 4ull,
+            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        a.tile_done[bid] = 1;
+        __hip_atomic_fetch_add(
+            reinterpret_cast<unsigned long long *>(a.filter_ctrl + kCtrlTotalEarly), 1ull,
+            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    return;
+  }
 
-  // The clamped repeats of the last stage must have landed before the stages
-  // become the epilogue's scratch.
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-  __syncthreads();
+  // This tile runs to its end here: the fallback launch has nothing to do for it.
+  // (The tiles of remainder pieces are marked by the host.)
+  if (!split && a.tile_done != nullptr && threadIdx.x == 0) a.tile_done[bid] = 1;
 
   if (split) {
     // Park this piece (16-byte write-through stores, [4 registers][thread]), take
@@ -600,12 +781,12 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
       }
     if (__ballot(best > 0.f) == 0) {  // wave-uniform
       if (lane == 0)
-        __hip_atomic_fetch_add(a.filter_ctrl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.filter_ctrl + kCtrlFinished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
   }
   if (lane == 0)
-    __hip_atomic_fetch_add(a.filter_ctrl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(a.filter_ctrl + kCtrlFinished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   uint32_t total = 0, base = 0, run = 0;  // wave-uniform
 #pragma nounroll
@@ -653,7 +834,7 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
           got = __hip_atomic_fetch_add(a.filter_ctrl, total, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
           // (running total since the scratch was allocated: "filter_candidates")
-          __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.filter_ctrl + 4),
+          __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.filter_ctrl + kCtrlTotalCand),
                                  (unsigned long long)total, __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -667,10 +848,10 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
       }
       if (dense) {
         if (lane == 0) {
-          const uint32_t slot = __hip_atomic_fetch_add(a.filter_ctrl + 1, 1u, __ATOMIC_RELAXED,
+          const uint32_t slot = __hip_atomic_fetch_add(a.filter_ctrl + kCtrlDense, 1u, __ATOMIC_RELAXED,
                                                        __HIP_MEMORY_SCOPE_AGENT);
           if (slot < a.dense_cap) a.dense_list[slot] = make_uint2(2 * tr + wy, 2 * tc + wx);
-          __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.filter_ctrl + 6), 1ull,
+          __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.filter_ctrl + kCtrlTotalDense), 1ull,
                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         break;
@@ -745,14 +926,24 @@ __global__ __launch_bounds__(256) void king_refine_kernel(const TiledArgs a) {
 
 }  // namespace
 
+static std::atomic<uint32_t> g_check_min_steps{64};
+void set_filter_check_min_steps(uint32_t steps) { g_check_min_steps.store(steps); }
+
 hipError_t launch_sample_stats(const uint64_t *d_bit_sets, uint32_t words_per_sample,
                                const PlaneGeometry &geo, uint4 *d_planes, uint32_t s_begin,
                                uint32_t s_end, hipStream_t stream) {
   if (s_end > geo.s_stride) s_end = geo.s_stride;
   if (s_begin >= s_end) return hipSuccess;
   float2 *stats = const_cast<float2 *>(plane_stats(d_planes, geo));
+  float *prefix = const_cast<float *>(plane_prefix_u(d_planes, geo));
+  unsigned long long *sums = const_cast<unsigned long long *>(plane_cohort_sums(d_planes, geo));
+  uint32_t *steps = const_cast<uint32_t *>(plane_check_steps(d_planes, geo));
+  CheckWords cw;
+  const uint32_t all_steps = geo.k_words / 8;  // k-steps of 256 sites
+  for (uint32_t k = 0; k < kNumCheckShares; ++k)
+    cw.w[k] = 4 * check_step_of(all_steps, k, g_check_min_steps.load());
   sample_stats_kernel<<<dim3((s_end - s_begin + 3) / 4), dim3(256), 0, stream>>>(
-      d_bit_sets, words_per_sample, geo, stats, s_begin, s_end);
+      d_bit_sets, words_per_sample, geo, stats, prefix, sums, steps, cw, s_begin, s_end);
   return hipGetLastError();
 }
 
@@ -777,12 +968,25 @@ hipError_t launch_filter(const TiledArgs &args, uint64_t num_tiles, hipStream_t 
   uint64_t done = 0;
   while (done < num_tiles) {
     const uint64_t n = num_tiles - done < cap ? num_tiles - done : cap;
-    hipError_t e = hipMemsetAsync(args.filter_ctrl, 0, 16, stream);
+    hipError_t e = hipMemsetAsync(args.filter_ctrl, 0, kCtrlChunkBytes, stream);
+    if (e != hipSuccess) return e;
+    const bool checks = args.wg_words != nullptr && args.tile_done != nullptr;
+    if (checks) {
+      e = hipMemsetAsync(args.wg_words, 0, n * sizeof(uint32_t), stream);
+      if (e != hipSuccess) return e;
+      e = hipMemsetAsync(args.tile_done, 0, n, stream);
+    }
     if (e != hipSuccess) return e;
     TiledArgs a = args;
     a.tile_begin = args.tile_begin + done;
     a.quad = 0;
     a.tile_list = nullptr;
+    a.gate = nullptr;
+    a.skip_tiles = nullptr;
+    // check 0 (the forecast): for launches of fewer than 16 rounds, where the tiles that
+    // would have to give up make up most of the launch before anybody has finished
+    a.check0 = checks && (args.check0 == 2 || (args.check0 == 1 && n < 16ull * wgs)) ? 1u : 0u;
+    a.check1 = checks ? args.check1 : 0u;
     // Short launches: the tiles beyond whole rounds of one per CU would leave most
     // CUs idle for a whole tile time; each of them is cut into `parts` pieces of k
     // instead (same launch, behind the whole tiles).
@@ -827,6 +1031,12 @@ hipError_t launch_filter(const TiledArgs &args, uint64_t num_tiles, hipStream_t 
     a.fsplit_tile0 = (uint32_t)n_whole;
     a.fsplit_first = (uint32_t)grid;
     grid += (uint64_t)rest * parts;
+    // (the tiles of the remainder pieces never leave early: done as far as the fallback
+    //  launch is concerned)
+    if (checks && rest != 0) {
+      e = hipMemsetAsync(args.tile_done + n_whole, 1, rest, stream);
+      if (e != hipSuccess) return e;
+    }
     king_filter_kernel<<<dim3((uint32_t)grid), dim3(256), kFilterLdsBytes, stream>>>(a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -835,10 +1045,23 @@ hipError_t launch_filter(const TiledArgs &args, uint64_t num_tiles, hipStream_t 
     if (e != hipSuccess) return e;
     TiledArgs d = a;
     d.tile_list = a.dense_list;
-    d.tile_list_count = a.filter_ctrl + 1;
+    d.tile_list_count = a.filter_ctrl + kCtrlDense;
     d.tile_list_cap = a.dense_cap;
     e = launch_mfma_list(d, wgs, stream);
     if (e != hipSuccess) return e;
+    if (checks) {
+      // The fallback: every tile of the chunk that has not set its flag (it left at
+      // check 0, or never started because most quadrants of the launch had gone dense),
+      // in the four-product kernel's own order -- if there is any: the gate word.
+      TiledArgs f = a;
+      f.quad = 1;
+      f.tile_begin = a.tile_begin * 4;
+      f.gate = a.filter_ctrl + kCtrlGate;
+      f.skip_tiles = a.tile_done;
+      f.skip_base = a.tile_begin;
+      e = launch_mfma_gated(f, n * 4, wgs, stream);
+      if (e != hipSuccess) return e;
+    }
     done += n;
   }
   return hipSuccess;

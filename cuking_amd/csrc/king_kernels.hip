@@ -819,6 +819,13 @@ hipError_t launch_prepare_planes(uint32_t layout, const uint64_t *d_bit_sets,
   const dim3 grid(s_tile_end - s_tile_begin,
                   (geo.k_words + 2 * block_words - 1) / (2 * block_words));
   if (grid.y == 0) return hipSuccess;
+  if (layout == kLayoutNibbleStats && s_tile_begin == 0) {
+    // a conversion that starts at plane sample 0 starts the cohort's sums afresh
+    // (staged preparation: the later sample ranges add to them)
+    hipError_t e0 = hipMemsetAsync(
+        const_cast<unsigned long long *>(plane_cohort_sums(d_planes, geo)), 0, 64, stream);
+    if (e0 != hipSuccess) return e0;
+  }
   if (layout == kLayoutQuad)
     prepare_quads_kernel<<<grid, dim3(256), 0, stream>>>(
         d_bit_sets, words_per_sample, geo, d_planes, s_tile_begin);

@@ -319,12 +319,18 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
                            : x * a.xcd_chunk + j;
     if (bid >= a.launch_tiles) return;  // padding (uniform)
   }
-  // Tile-list mode (king_common.h): entries bid, bid + grid, ... of the list.
-  const bool listed = !SPLIT && a.tile_list != nullptr;
+  // Tile-list mode (king_common.h): entries bid, bid + grid, ... of the list.  The
+  // persistent mode (gate != nullptr) walks the launch's own enumeration the same way:
+  // units bid, bid + grid, ... of gate_count, or nothing at all when the gate is shut.
+  const bool listed = !SPLIT && (a.tile_list != nullptr || a.gate != nullptr);
   uint32_t list_count = 0;
   if (listed) {
-    list_count = *a.tile_list_count;
-    if (list_count > a.tile_list_cap) list_count = a.tile_list_cap;
+    if (a.gate != nullptr) {
+      list_count = *a.gate != 0 ? a.gate_count : 0u;  // (uniform: a scalar load)
+    } else {
+      list_count = *a.tile_list_count;
+      if (list_count > a.tile_list_cap) list_count = a.tile_list_cap;
+    }
     // Workgroups are dealt round-robin to the 8 XCDs: give the ones that share an
     // XCD (and its L2) CONSECUTIVE entries of every round -- the list is in tile
     // order more or less, neighbours share row / column strips.
@@ -1741,6 +1747,34 @@ hipError_t launch_mfma_list(const TiledArgs &args, uint32_t grid, hipStream_t st
   // ONE launch whatever the block limit (a test hook may set it below `grid`): the
   // workgroups stride over the list, a second launch would walk it again.
   const uint64_t cap = max_blocks_per_launch(256);
+  if (grid > cap) grid = (uint32_t)cap;
+  if (grid == 0) return hipErrorInvalidValue;
+  auto kernel = king_mfma_kernel<false, false, 0, true>;
+  static DeviceOnce attr_set;  // per device, see king_device.h
+  if (!attr_set.done()) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)kMfmaN4LdsBytes);
+    if (e != hipSuccess) return e;
+    attr_set.mark();
+  }
+  kernel<<<dim3(grid), dim3(256), kMfmaN4LdsBytes, stream>>>(a);
+  return hipGetLastError();
+}
+
+hipError_t launch_mfma_gated(const TiledArgs &args, uint64_t num_units, uint32_t grid,
+                             hipStream_t stream) {
+  if ((uint64_t)args.geo.k_words * 32 > kMfmaN4MaxSites || args.gate == nullptr ||
+      args.tile_list != nullptr || num_units > 0xFFFFFFFFull)
+    return hipErrorInvalidValue;
+  TiledArgs a = args;
+  a.split_tiles = a.split_whole = 0;
+  a.split_scratch = a.split_counters = nullptr;
+  a.xcd_chunk = 0;
+  a.dyn_tiles = a.dyn_wgs = 0;
+  a.launch_tiles = 0;
+  a.gate_count = (uint32_t)num_units;
+  const uint64_t cap = max_blocks_per_launch(256);  // (ONE launch, see launch_mfma_list)
   if (grid > cap) grid = (uint32_t)cap;
   if (grid == 0) return hipErrorInvalidValue;
   auto kernel = king_mfma_kernel<false, false, 0, true>;

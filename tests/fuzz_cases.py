@@ -105,12 +105,17 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
         qcap = int(rng.choice([384, 384, 0, 2]))
         ccap = int(rng.choice([1 << 20, 1 << 20, 0, 5]))
         smin = int(rng.choice([8, 1, 1]))      # remainder pieces of k even for short bitsets
+        # ... and its check points inside the k loop (forecast: off / short launches / always;
+        # rigorous: off / automatic / an entry of the share menu), for bitsets of >= 4 k-steps
+        chk0 = int(rng.choice([1, 0, 2, 2]))
+        chk1 = int(rng.choice([1, 0, 3, 5, 7, 9]))
         if case < first_case:
             continue
         tag = dict(fuzzer="run_general", seed=seed, case=case, n=n, m=m, split_factor=k,
                    shard=shard, thr=thr, kernel=kernel, variant=variant, counts_mode=mode,
                    xcd_swizzle=swizzle, band_rows=band, split_wgs=wgs, reuse_prepared=reuse,
-                   filter_quadrant_cap=qcap, filter_cand_cap=ccap, filter_split_min_steps=smin)
+                   filter_quadrant_cap=qcap, filter_cand_cap=ccap, filter_split_min_steps=smin,
+                   filter_check0=chk0, filter_check1=chk1, filter_check_min_steps=4)
         osm = pyoracle.submatrix(n, k, shard)
         bits = pyoracle.bitset_from_genotypes(geno, osm)
         exp, _, _ = pyoracle.compute(osm, bits, thr, threads=8)
@@ -124,6 +129,9 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
         ctx.set_option("filter_quadrant_cap", qcap)
         ctx.set_option("filter_cand_cap", ccap)
         ctx.set_option("filter_split_min_steps", smin)
+        ctx.set_option("filter_check0", chk0)
+        ctx.set_option("filter_check1", chk1)
+        ctx.set_option("filter_check_min_steps", 4)
         # (a new bitset may land on a recycled pointer: tell the library)
         ctx.set_option("reuse_prepared", reuse)
         ctx.invalidate()
@@ -156,6 +164,9 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
     ctx.set_option("filter_quadrant_cap", 384)
     ctx.set_option("filter_cand_cap", 1 << 25)
     ctx.set_option("filter_split_min_steps", 8)
+    ctx.set_option("filter_check0", 1)
+    ctx.set_option("filter_check1", 1)
+    ctx.set_option("filter_check_min_steps", 64)
     return ran
 
 

@@ -1231,6 +1231,79 @@ def test_filter_variant_tile_geometry_and_fallbacks(ctx, oracle):
     check_counts(ctx, oracle, sm, bits)
 
 
+@pytest.mark.parametrize("missing", [0.0, 0.02, 0.35])
+def test_filter_check_points_inside_the_k_loop(ctx, oracle, missing):
+    """The filter kernel's check points (king_filter.hip): after a share of the k-steps a
+    tile tests its sums against the bound over the sites so far.  The rigorous check lets a
+    tile none of whose pairs can still become a candidate leave (every term of the
+    numerator's X is non-negative); the forecast at an eighth of the sites sends a tile whose
+    quadrants look dense to the exact kernel at once -- computed by the fallback launch
+    (four-product kernel, persistent mode, gated on a device word) behind the filter
+    kernel.  Every entry of the share menu forced, the forecast forced, both, neither, with
+    and without the remainder pieces: the oracle's records every time; and the exits really
+    happen."""
+    select(ctx, "tiled", 7, counts_mode=0)
+    rng = np.random.default_rng(int(missing * 100) + 11)
+    n, m = 1100, 6200                         # 5 x 5 tiles of 256; 25 k-steps of 256 sites
+    geno = random_genotypes(rng, n, m, missing=missing)
+    for k in range(12):                        # a family inside one quadrant, relatives across tiles
+        geno[300 + k] = np.where(rng.random(m) < 0.02, geno[5], geno[300])
+    geno[n - 1], geno[700], geno[1023] = geno[2], geno[130], geno[256]
+    bits = oracle.bitset_from_genotypes(geno)
+    d_bits = ctx.upload_bitset(bits)
+    sm = cuking_amd.Submatrix(n)
+    off = cuking_amd.Submatrix(n, 2, 1)
+    idx = list(range(off.i_begin, off.i_end)) + list(range(off.j_begin, off.j_end))
+    sub = np.ascontiguousarray(bits[idx])
+    d_sub = ctx.upload_bitset(sub)
+    defaults = {"filter_check0": 1, "filter_check1": 1, "filter_split_min_steps": 8,
+                "max_launch_blocks": 0, "filter_quadrant_cap": 384, "split_wgs": 256}
+    ctx.set_option("filter_check_min_steps", 4)
+    try:
+        for thr in (0.03, 0.0884, 0.2):
+            exp, _, _ = oracle.compute(oracle.submatrix(n), bits, thr, threads=16)
+            e2, _, _ = oracle.compute(oracle.submatrix(n, 2, 1), sub, thr, threads=16)
+            assert len(exp) >= 12 * 11 // 2
+            # (15 tiles on 256 CUs: with remainder splitting every tile goes out as pieces of
+            #  k, which have no check points -- "split_wgs": 0 sends whole tiles)
+            cases = [{}, {"filter_check0": 0, "filter_check1": 0}, {"filter_check0": 2},
+                     {"filter_check0": 2, "split_wgs": 0},
+                     {"filter_check0": 2, "filter_check1": 0, "split_wgs": 0},
+                     {"filter_check0": 2, "filter_quadrant_cap": 0, "split_wgs": 0},
+                     {"filter_check0": 2, "filter_check1": 5, "filter_split_min_steps": 1},
+                     {"filter_check0": 2, "max_launch_blocks": 4, "split_wgs": 0}]
+            cases += [{"filter_check0": 0, "filter_check1": 2 + k, "split_wgs": 0}
+                      for k in range(1, 8)]
+            for opts in cases:
+                for k, v in {**defaults, **opts}.items():
+                    ctx.set_option(k, v)
+                exits0 = ctx.get_option("filter_early_exits")
+                dense0 = ctx.get_option("filter_dense_quadrants")
+                got = ctx.run(sm, bits.shape[1], d_bits, thr, max_results=1 << 20)
+                assert got.tobytes() == exp.tobytes(), (thr, opts)
+                exits = ctx.get_option("filter_early_exits") - exits0
+                dense = ctx.get_option("filter_dense_quadrants") - dense0
+                whole = opts.get("split_wgs") == 0
+                if missing == 0.0 and thr == 0.2 and opts.get("filter_check1", 1) >= 3 and whole:
+                    # unrelated samples sit near kinship 0: from ~0.7 of the sites on no pair of
+                    # a tile without relatives can reach 0.2.  Of the 15 tiles the 5 on the
+                    # diagonal always hold a live pair (a sample against itself), 3 hold planted
+                    # duplicates -- (0, 2), (0, 4), (1, 3) --: the other 7 leave.
+                    assert exits == 7, (thr, opts, exits)
+                if missing == 0.35 and opts.get("filter_check0") == 2 and whole and \
+                        "max_launch_blocks" not in opts:
+                    # the bound thins nothing out: every tile leaves at the forecast (counted
+                    # as 4 quadrants each) and the fallback launch computes all of them
+                    assert dense == 4 * 15, (thr, opts, dense)
+                got = ctx.run(off, bits.shape[1], d_sub, thr, max_results=1 << 20)
+                assert got.tobytes() == e2.tobytes(), (thr, opts, "off-diagonal block")
+    finally:
+        ctx.set_option("filter_check_min_steps", 64)
+        for k, v in defaults.items():
+            ctx.set_option(k, v)
+        ctx.set_option("counts_mode", -1)
+
+
 @pytest.mark.parametrize("missing,thr", [(0.35, 0.05), (0.02, 0.004), (0.03, 0.07), (0.03, 0.085)])
 def test_filter_variant_gives_up_on_a_cohort_its_bound_cannot_thin_out(ctx, oracle, missing, thr):
     """Heavy missingness, or a threshold inside the noise of unrelated pairs: nearly every
