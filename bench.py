@@ -80,7 +80,7 @@ NUM_SIMDS = 256 * 4
 # when kin_threshold > 0), full form 5 + 5.
 VALU_OPS_PER_PAIR_WORD = {"lean": 9, "full": 10}
 # VALU issue floor, measured on MI355X (tools/micro/king_step.hip, valu_phase.hip;
-# profiles/r01_valu_microbench.txt), cycles per wave64 instruction per SIMD:
+# archive/profiles/r01_valu_microbench.txt), cycles per wave64 instruction per SIMD:
 # v_and 2.07, v_bitop3 2.37, v_bcnt_u32_b32 4.19 when each kind runs alone.
 VALU_FLOOR_CYCLES_PER_PAIR_WORD = {"lean": 4 * 2.07 + 2.37 + 4 * 4.19,
                                    "full": 4 * 2.07 + 2.37 + 5 * 4.19}

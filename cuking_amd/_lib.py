@@ -54,6 +54,11 @@ SIGNATURES = {
     "cuking_pack_host": (_int, [_SM, _u32, _vp, _vp, _vp, _vp, _sz]),
     "cuking_narrow_triples": (_int, [_SM, _u32, _vp, _vp, _vp, _sz, _vp, _vp,
                                      C.POINTER(_sz)]),
+    "cuking_schedule_tile_partition": (None, [_u64, _u32, _vp]),
+    "cuking_schedule_weighted_tile_partition": (_int, [_u64, _vp, _u32, _vp]),
+    "cuking_schedule_calibration_tiles": (_u64, [_u64, _u32]),
+    "cuking_schedule_chunk_ranges": (_u32, [_u32, _u32, _u32, _vp]),
+    "cuking_schedule_staged_steps": (_u32, [_u32, _u32, _u32, _u32, _u32, _vp]),
     "cuking_last_error": (C.c_char_p, []),
     "cuking_abi_version": (_u32, []),
     "cuking_device_count": (_int, []),

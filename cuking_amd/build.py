@@ -26,7 +26,8 @@ CLI_PATH = PKG / "bin" / "cuking"
 # -D flags; the next default build must not mistake that file for its own.
 LIB_FLAGS_PATH = PKG / "libcuking_amd.flags"
 
-HIP_SOURCES = ["king_abi.hip", "king_kernels.hip", "king_mfma.hip", "king_filter.hip", "synth.hip"]
+HIP_SOURCES = ["king_abi.hip", "king_kernels.hip", "king_mfma.hip", "king_filter.hip",
+               "king_sort.hip", "synth.hip"]
 # Host-only half of the ABI: plain C++, also compiled by the sanitizer tests.
 HOST_ABI_SOURCES = ["king_host.cc"]
 # IEEE-correct fp32 divide (kinship must match the reference bit for bit):

@@ -125,6 +125,12 @@ struct cuking_ctx {
   // launches of fewer than 16 rounds, 2 always; check 1 (rigorous) 0 off, 1 the entry the
   // kernel picks from threshold and cohort, 2 + k entry k of the share menu forced.
   int filter_check0 = 1, filter_check1 = 1;
+  // The kernel layout's samples sorted by their share of missing calls (king_sort.hip);
+  // the four-product kernel's codes converted only when the filter needs them
+  // (0: with every conversion).
+  bool filter_sort = true, filter_lazy_codes = true;
+  void *sort_temp = nullptr;
+  size_t sort_temp_bytes = 0;
 
   // What the plane workspace holds: the block it was converted for and which
   // 64-sample plane tiles of it have been converted (cuking_compute_king_rect
@@ -136,6 +142,7 @@ struct cuking_ctx {
     int variant = -1;
     uint32_t tile = 0;  // tile edge of the geometry (the context variant's)
     const uint64_t *bits = nullptr;
+    bool codes = true;  // every converted tile has its nibble codes (false: T2 only, lazy)
     // per 64 plane samples: 0 = not converted, 1 = converted (kernels that
     // read it, if any, all precede the tail of `ordered_on`), 2 = converted
     // and read by kernels enqueued since
@@ -239,7 +246,7 @@ PlaneGeometry make_geometry(const cuking_submatrix &sm,
 }
 
 // Band height when the caller has not pinned one.  Measured on MI355X with the
-// XCD-aware order (profiles/r02_xcd_order.txt): the matrix-core kernel wants
+// XCD-aware order (archive/profiles/r02_xcd_order.txt): the matrix-core kernel wants
 // the 32 tiles an XCD holds at a time to be a compact patch, 5 rows x ~6
 // columns (11 strips through one L2 instead of 32): 100k x 100k 645 -> 621 ms,
 // 300k x 150k 9.33 -> 8.69 s.  Below ~128 tile rows the bitset sits in the
@@ -393,6 +400,16 @@ cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const Plan
   return CUKING_OK;
 }
 
+// The sample order of the workspace's layout, and the lazy-codes word, for the launch.
+void layout_order_for(const cuking_ctx *ctx, uint32_t words_per_sample, const PlaneGeometry &geo,
+                      TiledArgs *a) {
+  a->perm = nullptr;
+  a->codes_ready = nullptr;
+  if (plan_variant(ctx, words_per_sample).layout != kLayoutNibbleStats) return;
+  a->perm = plane_perm(ctx->planes, geo);
+  if (!ctx->prepared.codes) a->codes_ready = plane_flags(ctx->planes, geo);
+}
+
 // Enqueues `num_tiles` tiles of the planned geometry: as they are when the
 // kernel's tile edge is the geometry's, as four quadrants each otherwise.
 hipError_t launch_planned(const cuking_ctx *ctx, uint32_t words_per_sample, bool full,
@@ -501,6 +518,21 @@ cuking_status ensure_workspace(cuking_ctx *ctx, size_t need, size_t entries) {
   return CUKING_OK;
 }
 
+// Device scratch of the sample sort for ranges of up to `n` samples.
+cuking_status ensure_sort_temp(cuking_ctx *ctx, uint32_t n) {
+  const size_t need = sort_temp_bytes_for(n);
+  if (need <= ctx->sort_temp_bytes) return CUKING_OK;
+  ++ctx->host_syncs;
+  HIP_TRY(hipDeviceSynchronize());
+  if (ctx->sort_temp) HIP_TRY(hipFree(ctx->sort_temp));
+  ctx->sort_temp = nullptr;
+  ctx->sort_temp_bytes = 0;
+  HIP_TRY(hipMalloc(&ctx->sort_temp, need));
+  ++ctx->workspace_allocations;
+  ctx->sort_temp_bytes = need;
+  return CUKING_OK;
+}
+
 bool same_tile_space(const TileSpace &a, const TileSpace &b) {
   return a.tiles_r == b.tiles_r && a.tiles_c == b.tiles_c && a.band_rows == b.band_rows &&
          a.diag == b.diag;
@@ -522,10 +554,34 @@ cuking_status upload_prefix(cuking_ctx *ctx, const TileSpace &tiles, hipStream_t
 }
 
 // Builds planes + band prefix for `sm` in the context workspace.
+// The nibble codes (+ het-only copy) of every converted tile of a kLayoutNibbleStats
+// workspace whose last conversion left them out (lazy codes): for calls that run the
+// four-product kernel directly.
+cuking_status convert_codes_now(cuking_ctx *ctx, const PlaneGeometry &geo,
+                                uint32_t words_per_sample, const uint64_t *d_bit_sets,
+                                hipStream_t stream) {
+  cuking_ctx::Prepared &pr = ctx->prepared;
+  const uint32_t all = (uint32_t)pr.tiles.size();
+  for (uint32_t t = 0; t < all;) {
+    if (pr.tiles[t] == 0) {
+      ++t;
+      continue;
+    }
+    uint32_t e = t;
+    while (e < all && pr.tiles[e] != 0) ++e;
+    HIP_TRY(launch_prepare_nibbles(true, false, d_bit_sets, words_per_sample, geo, ctx->planes,
+                                   plane_perm(ctx->planes, geo), t, e, nullptr, nullptr, stream));
+    t = e;
+  }
+  HIP_TRY(hipMemsetAsync(plane_flags(ctx->planes, geo), 1, sizeof(uint32_t), stream));
+  pr.codes = true;
+  return CUKING_OK;
+}
+
 cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
                       uint32_t words_per_sample, const uint64_t *d_bit_sets,
                       hipStream_t stream, PlaneGeometry *geo_out,
-                      TileSpace *tiles_out, uint32_t s_tile_begin = 0,
+                      TileSpace *tiles_out, bool need_codes, uint32_t s_tile_begin = 0,
                       uint32_t s_tile_end = 0xFFFFFFFFu) {
   const int variant = effective_variant(ctx, words_per_sample);
   const TiledVariant v = plan_variant(ctx, words_per_sample);
@@ -538,6 +594,10 @@ cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
   const uint32_t nb = tiles.num_bands();
   cuking_status st = ensure_workspace(ctx, need, (size_t)nb + 1);
   if (st != CUKING_OK) return st;
+  if (v.layout == kLayoutNibbleStats && ctx->filter_sort) {
+    st = ensure_sort_temp(ctx, geo.s_stride);
+    if (st != CUKING_OK) return st;
+  }
   // Book-keeping of what the workspace holds, and ordering against kernels on
   // other streams that still read what is about to be overwritten -- the planes
   // AND the band prefix below, so this comes before either is touched.
@@ -554,6 +614,8 @@ cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
     for (uint32_t t = s_tile_begin; t < t_end && all_there; ++t) all_there = pr.tiles[t] != 0;
     if (all_there) {
       ++ctx->conversions_skipped;
+      if (v.layout == kLayoutNibbleStats && need_codes && !pr.codes)
+        return convert_codes_now(ctx, geo, words_per_sample, d_bit_sets, stream);
       return CUKING_OK;
     }
   }
@@ -572,6 +634,7 @@ cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
     pr.tile = v.tile;
     pr.bits = d_bit_sets;
     pr.tiles.assign(all_tiles, 0);
+    pr.codes = true;
   }
   for (uint32_t t = s_tile_begin; t < t_end; ++t)
     must_wait = must_wait || pr.tiles[t] == 2 || (pr.tiles[t] == 1 && other_stream);
@@ -588,8 +651,39 @@ cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
   if (need == 0) return CUKING_OK;
   EventPair *ev = nullptr;
   if (ctx->timing) HIP_TRY(ctx->prepare_timer.begin(stream, &ev));
-  HIP_TRY(launch_prepare_planes(v.layout, d_bit_sets, words_per_sample, geo, ctx->planes,
-                                s_tile_begin, s_tile_end, stream));
+  if (v.layout == kLayoutNibbleStats) {
+    // The filter variant's layout, step by step: statistics in stored order, the sample
+    // order (king_sort.hip), T2 -- and the four-product kernel's codes now, or by a gated
+    // launch behind the filter kernel if that turns out to need them (lazy codes: whole
+    // blocks only; the ranges of a staged pass are converted in full).
+    const bool whole = s_tile_begin == 0 && t_end == all_tiles;
+    const bool codes = need_codes || !ctx->filter_lazy_codes || !whole;
+    const uint32_t sb = s_tile_begin * 64, se = t_end * 64;
+    if (s_tile_begin == 0)  // a conversion that starts at plane sample 0 starts the cohort's sums afresh
+      HIP_TRY(hipMemsetAsync(const_cast<unsigned long long *>(plane_cohort_sums(ctx->planes, geo)),
+                             0, 64, stream));
+    // (whatever is converted now, the codes of the block as a whole are not "there" unless
+    //  this conversion or convert_codes_now() below says so)
+    HIP_TRY(hipMemsetAsync(plane_flags(ctx->planes, geo), 0, sizeof(uint32_t), stream));
+    HIP_TRY(launch_sample_stats(d_bit_sets, words_per_sample, geo, ctx->planes, sb, se, stream));
+    HIP_TRY(launch_sample_order(geo, words_per_sample, ctx->planes, sb, se, ctx->filter_sort,
+                                ctx->sort_temp, ctx->sort_temp_bytes, stream));
+    HIP_TRY(launch_prepare_nibbles(codes, true, d_bit_sets, words_per_sample, geo, ctx->planes,
+                                   plane_perm(ctx->planes, geo), s_tile_begin, t_end, nullptr,
+                                   nullptr, stream));
+    if (!codes) {
+      pr.codes = false;
+    } else if (!pr.codes) {
+      // earlier tiles of this block were converted without codes: complete them
+      st = convert_codes_now(ctx, geo, words_per_sample, d_bit_sets, stream);
+      if (st != CUKING_OK) return st;
+    } else {
+      HIP_TRY(hipMemsetAsync(plane_flags(ctx->planes, geo), 1, sizeof(uint32_t), stream));
+    }
+  } else {
+    HIP_TRY(launch_prepare_planes(v.layout, d_bit_sets, words_per_sample, geo, ctx->planes,
+                                  s_tile_begin, s_tile_end, stream));
+  }
   if (ev) HIP_TRY(hipEventRecord(ev->stop, stream));
   return CUKING_OK;
 }
@@ -603,8 +697,12 @@ cuking_status run_tiled(cuking_ctx *ctx, const cuking_submatrix &sm,
                         hipStream_t stream) {
   PlaneGeometry geo;
   TileSpace tiles;
+  const bool full = use_full_counts(ctx, kin_threshold, d_counts != nullptr, words_per_sample);
+  // (the filter's bound applies: the four-product kernel's codes may stay unconverted)
+  const bool filter_runs = effective_variant(ctx, words_per_sample) == kMfmaFilterVariant &&
+                           !full && kin_threshold > 0.f && kin_threshold < 0.5f;
   cuking_status st =
-      prepare(ctx, sm, words_per_sample, d_bit_sets, stream, &geo, &tiles);
+      prepare(ctx, sm, words_per_sample, d_bit_sets, stream, &geo, &tiles, !filter_runs);
   if (st != CUKING_OK) return st;
   const uint64_t n_tiles = total_tiles(tiles);
   if (whole) {
@@ -647,12 +745,11 @@ cuking_status run_tiled(cuking_ctx *ctx, const cuking_submatrix &sm,
   if (st != CUKING_OK) return st;
   st = filter_scratch_for(ctx, stream, geo, n_tiles, &a);
   if (st != CUKING_OK) return st;
+  layout_order_for(ctx, words_per_sample, geo, &a);
 
   EventPair *ev = nullptr;
   if (ctx->timing) HIP_TRY(ctx->king_timer.begin(stream, &ev));
-  HIP_TRY(launch_planned(ctx, words_per_sample,
-                         use_full_counts(ctx, kin_threshold, d_counts != nullptr, words_per_sample), a,
-                         tile_end - tile_begin, stream));
+  HIP_TRY(launch_planned(ctx, words_per_sample, full, a, tile_end - tile_begin, stream));
   note_reader(ctx, stream);
   mark_read(ctx, 0, 0xFFFFFFFFu);
   if (ev) HIP_TRY(hipEventRecord(ev->stop, stream));
@@ -733,6 +830,7 @@ void cuking_ctx_destroy(cuking_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->planes) (void)hipFree(ctx->planes);
   if (ctx->band_prefix) (void)hipFree(ctx->band_prefix);
+  if (ctx->sort_temp) (void)hipFree(ctx->sort_temp);
   for (auto &e : ctx->split_scratch) (void)hipFree(e.second);
   for (auto &e : ctx->filter_scratch) (void)hipFree(e.base);
   for (auto &r : ctx->readers)
@@ -819,6 +917,13 @@ cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
       return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "filter_check_min_steps outside [4, 2^20]");
     set_filter_check_min_steps((uint32_t)value);
     ctx->prepared.valid = false;  // (prefix counts of the workspace belong to the old value)
+    return CUKING_OK;
+  }
+  if (strcmp(key, "filter_sort") == 0 || strcmp(key, "filter_lazy_codes") == 0) {
+    if (value < 0 || value > 1)
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "%s outside [0, 1]", key);
+    (strcmp(key, "filter_sort") == 0 ? ctx->filter_sort : ctx->filter_lazy_codes) = value != 0;
+    ctx->prepared.valid = false;  // (the workspace was laid out under the old setting)
     return CUKING_OK;
   }
   if (strcmp(key, "filter_check0") == 0) {  // forecast check: 0 off, 1 short launches, 2 always
@@ -1067,6 +1172,8 @@ cuking_status cuking_ctx_get_option(const cuking_ctx *ctx, const char *key,
   else if (strcmp(key, "filter_quadrant_cap") == 0) *value = ctx->filter_quadrant_cap;
   else if (strcmp(key, "filter_cand_cap") == 0) *value = ctx->filter_cand_cap;
   else if (strcmp(key, "filter_split_min_steps") == 0) *value = ctx->filter_split_min_steps;
+  else if (strcmp(key, "filter_sort") == 0) *value = ctx->filter_sort ? 1 : 0;
+  else if (strcmp(key, "filter_lazy_codes") == 0) *value = ctx->filter_lazy_codes ? 1 : 0;
   else if (strcmp(key, "filter_check0") == 0) *value = ctx->filter_check0;
   else if (strcmp(key, "filter_check1") == 0) *value = ctx->filter_check1;
   else if (strcmp(key, "filter_candidates") == 0 || strcmp(key, "filter_dense_quadrants") == 0 ||
@@ -1193,7 +1300,7 @@ cuking_status cuking_prepare_samples(cuking_ctx *ctx, const cuking_submatrix *sm
   TileSpace tiles;
   // prepare() works in units of 64 plane samples.
   return prepare(ctx, *sm, words_per_sample, d_bit_sets, (hipStream_t)stream, &geo,
-                 &tiles, t0 * (tile / 64), t1 * (tile / 64));
+                 &tiles, true, t0 * (tile / 64), t1 * (tile / 64));
 }
 
 cuking_status cuking_compute_king_rect(
@@ -1293,11 +1400,20 @@ cuking_status cuking_compute_king_rect(
   if (st != CUKING_OK) return st;
   st = filter_scratch_for(ctx, (hipStream_t)stream, geo, total_tiles(make_tiles(geo, v, ctx->band_rows)), &a);
   if (st != CUKING_OK) return st;
+  layout_order_for(ctx, words_per_sample, geo, &a);
+  const bool full = use_full_counts(ctx, kin_threshold, false, words_per_sample);
+  if (v.layout == kLayoutNibbleStats && !ctx->prepared.codes &&
+      !(variant == kMfmaFilterVariant && !full && kin_threshold > 0.f && kin_threshold < 0.5f)) {
+    // (a block converted without the four-product kernel's codes, and a call that runs
+    //  that kernel directly)
+    st = convert_codes_now(ctx, geo, words_per_sample, d_bit_sets, (hipStream_t)stream);
+    if (st != CUKING_OK) return st;
+    a.codes_ready = nullptr;
+  }
   EventPair *ev = nullptr;
   if (ctx->timing) HIP_TRY(ctx->king_timer.begin((hipStream_t)stream, &ev));
-  HIP_TRY(launch_planned(ctx, words_per_sample,
-                         use_full_counts(ctx, kin_threshold, false, words_per_sample), a,
-                         (uint64_t)n_rows * (c1 - c0), (hipStream_t)stream));
+  HIP_TRY(launch_planned(ctx, words_per_sample, full, a, (uint64_t)n_rows * (c1 - c0),
+                         (hipStream_t)stream));
   note_reader(ctx, (hipStream_t)stream);
   {
     const uint32_t per = v.tile / 64;
@@ -1323,6 +1439,10 @@ cuking_status cuking_ctx_reserve(cuking_ctx *ctx, const cuking_submatrix *sm,
   const TileSpace tiles = make_tiles(geo, v, ctx->band_rows);
   st = ensure_workspace(ctx, plane_bytes(geo, v.layout), (size_t)tiles.num_bands() + 1);
   if (st != CUKING_OK) return st;
+  if (v.layout == kLayoutNibbleStats && ctx->filter_sort) {
+    st = ensure_sort_temp(ctx, geo.s_stride);
+    if (st != CUKING_OK) return st;
+  }
   if (!same_tile_space(ctx->prefix_for, tiles)) {
     // (nothing may be reading another block's prefix: the caller reserves
     //  before it enqueues work for this block)

@@ -236,6 +236,19 @@ struct TiledArgs {
   uint32_t gate_count;
   const uint8_t *skip_tiles;
   uint64_t skip_base;
+  // Sample order of the kernel layout (kLayoutNibbleStats workspaces; nullptr: as
+  // stored).  perm[p] = which stored sample of the block (row samples first, then the
+  // columns of an off-diagonal block: the index into `bits`) sits at plane sample p, or
+  // 0xFFFFFFFF for padding.  The conversion sorts the samples of a prepared range by
+  // their share of missing calls (king_sort.hip), so that the few low-call-rate samples
+  // of a cohort -- whose pairs the filter's bound cannot rule out -- fill a few tile rows
+  // instead of spoiling every quadrant.  Pairs are enumerated in plane order (i < j there);
+  // a record carries the original indices, smaller first.
+  const uint32_t *perm;
+  // Lazy codes (filter variant): the four-product kernel's nibble codes are converted by a
+  // gated launch behind the filter kernel only if a quadrant went dense or a tile left
+  // (codes_ready: device word, 1 once they are there for the prepared block).
+  uint32_t *codes_ready;
 };
 
 // Prefix statistics: the k-steps (of 256 sites) a check may sit behind, as shares of the
@@ -264,7 +277,9 @@ __host__ __device__ inline size_t plane_bytes(const PlaneGeometry &g,
   if (layout == kLayoutNibble) return base + base / 4;  // + the het-only copy
   if (layout == kLayoutNibbleStats)
     return base + base / 4 + base / 2 + (size_t)g.s_stride * sizeof(float2) +
-           (size_t)g.s_stride * kNumCheckShares * sizeof(float) + 64 + 64;
+           (size_t)g.s_stride * kNumCheckShares * sizeof(float) + 64 + 64 +
+           // control block, perm, statistics before the sort, the sort's four arrays
+           64 + (size_t)g.s_stride * (4 + 8 + 4 * kNumCheckShares + 16);
   return base;
 }
 // Where the T2 layout and the per-sample statistics of kLayoutNibbleStats start
@@ -352,6 +367,27 @@ __host__ __device__ inline const uint32_t *plane_check_steps(const uint4 *planes
                                                              const PlaneGeometry &g) {
   return reinterpret_cast<const uint32_t *>(plane_cohort_sums(planes, g) + 8);
 }
+// ... one control block (16 u32; word 0: codes_ready), then the sample order and what
+// building it needs, every array s_stride entries long: perm (u32), the statistics in
+// stored order before the sort (float2, then kNumCheckShares floats), keys in / out and
+// values in / out of the sort (u32 each).
+__host__ __device__ inline uint32_t *plane_flags(const uint4 *planes, const PlaneGeometry &g) {
+  return const_cast<uint32_t *>(plane_check_steps(planes, g)) + 16;
+}
+__host__ __device__ inline uint32_t *plane_perm(const uint4 *planes, const PlaneGeometry &g) {
+  return plane_flags(planes, g) + 16;
+}
+__host__ __device__ inline float2 *plane_tmp_stats(const uint4 *planes, const PlaneGeometry &g) {
+  return reinterpret_cast<float2 *>(plane_perm(planes, g) + g.s_stride);
+}
+__host__ __device__ inline float *plane_tmp_prefix(const uint4 *planes, const PlaneGeometry &g) {
+  return reinterpret_cast<float *>(plane_tmp_stats(planes, g) + g.s_stride);
+}
+__host__ __device__ inline uint32_t *plane_sort_words(const uint4 *planes, const PlaneGeometry &g) {
+  return reinterpret_cast<uint32_t *>(plane_tmp_prefix(planes, g) +
+                                      (size_t)g.s_stride * kNumCheckShares);
+}
+constexpr uint32_t kNoSample = 0xFFFFFFFFu;
 
 // Scratch of one stream: control words, tickets, one word and one flag per tile of a
 // launch chunk, the candidate list, the dense-quadrant list, the remainder slabs.  The
@@ -412,6 +448,24 @@ hipError_t launch_sample_stats(const uint64_t *d_bit_sets, uint32_t words_per_sa
                                uint32_t s_end, hipStream_t stream);
 // Test hook, process-wide: bitsets of fewer k-steps get no check points (default 64).
 void set_filter_check_min_steps(uint32_t steps);
+// The sample order of plane samples [s_begin, s_end) of a kLayoutNibbleStats workspace
+// (king_sort.hip): statistics in stored order -> keys -> stable sort (or none) -> perm and
+// the statistics in plane order.  `sort_temp` / `sort_temp_bytes`: device scratch of at
+// least sort_temp_bytes_for(s_end - s_begin).
+size_t sort_temp_bytes_for(uint32_t n);
+hipError_t launch_sample_order(const PlaneGeometry &geo, uint32_t words_per_sample,
+                               uint4 *d_planes, uint32_t s_begin, uint32_t s_end, bool sort,
+                               void *sort_temp, size_t sort_temp_bytes, hipStream_t stream);
+// Codes (+ het-only copy) and / or T2 of plane tiles [s_tile_begin, s_tile_end) of a
+// nibble workspace; `gate` != nullptr: only if a quadrant went dense or a tile left
+// (filter control words) and the codes are not there yet (*ready == 0).
+hipError_t launch_prepare_nibbles(bool codes, bool t2, const uint64_t *d_bit_sets,
+                                  uint32_t words_per_sample, const PlaneGeometry &geo,
+                                  uint4 *d_planes, const uint32_t *perm, uint32_t s_tile_begin,
+                                  uint32_t s_tile_end, const uint32_t *gate,
+                                  const uint32_t *ready, hipStream_t stream);
+// *ready = 1 if the gate is open (behind a gated launch_prepare_nibbles).
+hipError_t launch_mark_codes_ready(const uint32_t *gate, uint32_t *ready, hipStream_t stream);
 // Bytes of split scratch (counters, then slabs) for `wgs` workgroups, and of
 // the counter part alone (the only part that must start out zero).
 size_t mfma_split_scratch_bytes(uint32_t wgs);

@@ -75,7 +75,7 @@ __device__ __forceinline__ uint32_t wave_hom_hom_count(
   // The loop is one memory latency per trip (the planes of an arbitrary pair
   // are cold), so a trip requests 2 x 8 words per lane before it counts any:
   // a 100k-site pair takes 4 trips instead of 25 (tiles with ~40 related pairs
-  // spent 350 us here, profiles/r02_tail.txt).
+  // spent 350 us here, archive/profiles/r02_tail.txt).
   constexpr uint32_t kAhead = 8;
   for (uint32_t w0 = 0; w0 < n; w0 += 64 * kAhead) {  // (uniform trip count)
     uint64_t x[kAhead], y[kAhead];
@@ -158,6 +158,40 @@ struct EmitCtx {
   uint32_t diag, num_rows;
   uint32_t i_begin, j_begin;
 };
+// ... plus the sample order of the layout (king_common.h `perm`, or nullptr): the
+// four-product kernel's epilogues, which may run on a sorted layout.  (A type of its own:
+// two more live registers in the five-product full form's epilogue were enough for the
+// allocator to park its k loop's LDS offsets in scratch and reload them inside the loop.)
+struct EmitCtxP : EmitCtx {
+  const uint32_t *perm;
+};
+
+// The stored sample (index into `bits`: rows first, then an off-diagonal block's columns)
+// behind row / column plane index li / lj of the block.
+__device__ __forceinline__ uint32_t stored_row(const EmitCtx &, uint32_t li) { return li; }
+__device__ __forceinline__ uint32_t stored_col(const EmitCtx &c, uint32_t lj) {
+  return c.diag ? lj : c.num_rows + lj;
+}
+__device__ __forceinline__ uint32_t stored_row(const EmitCtxP &c, uint32_t li) {
+  return c.perm != nullptr ? c.perm[li] : li;
+}
+__device__ __forceinline__ uint32_t stored_col(const EmitCtxP &c, uint32_t lj) {
+  // (a sorted layout is the filter variant's: 256-sample tiles, the columns of an
+  //  off-diagonal block behind the padded rows)
+  return c.perm != nullptr
+             ? c.perm[(c.diag ? 0u : (c.num_rows + kFilterTile - 1) / kFilterTile * kFilterTile) + lj]
+             : (c.diag ? lj : c.num_rows + lj);
+}
+// The record's (sample_i, sample_j) for stored samples (si, sj): global indices, smaller
+// first (a sorted layout enumerates a diagonal block's pairs in plane order; every field
+// of a record is symmetric in the two samples).
+__device__ __forceinline__ void record_pair(const EmitCtx &c, uint32_t si, uint32_t sj,
+                                            uint32_t *gi, uint32_t *gj) {
+  const uint32_t a = c.i_begin + si;
+  const uint32_t b = c.diag ? c.j_begin + sj : c.j_begin + (sj - c.num_rows);
+  *gi = a < b ? a : b;
+  *gj = a < b ? b : a;
+}
 
 __device__ __forceinline__ EmitCtx make_emit_ctx(const TiledArgs &a) {
   EmitCtx c;
@@ -172,6 +206,12 @@ __device__ __forceinline__ EmitCtx make_emit_ctx(const TiledArgs &a) {
   c.num_rows = a.geo.num_rows;
   c.i_begin = a.i_begin;
   c.j_begin = a.j_begin;
+  return c;
+}
+__device__ __forceinline__ EmitCtxP make_emit_ctx_p(const TiledArgs &a) {
+  EmitCtxP c;
+  static_cast<EmitCtx &>(c) = make_emit_ctx(a);
+  c.perm = a.perm;
   return c;
 }
 
@@ -192,16 +232,16 @@ __device__ __forceinline__ void lean_epilogue_pair(
     pending &= pending - 1;
     const uint32_t p_li = __builtin_amdgcn_readlane(li, src);
     const uint32_t p_lj = __builtin_amdgcn_readlane(lj, src);
-    const uint32_t off_j = a.diag ? p_lj : a.num_rows + p_lj;
-    const uint32_t sum =
-        wave_hom_hom_count(a.bits, a.words_per_sample, p_li, off_j, lane);
+    const uint32_t sum = wave_hom_hom_count(a.bits, a.words_per_sample, stored_row(a, p_li),
+                                            stored_col(a, p_lj), lane);
     if ((int)lane == src) hom_hom = sum;
   }
   if (emit) {
     const uint32_t ibs0 = opp, ibs2 = hom_hom - opp + both_het;
-    emit_result(a.i_begin + li, a.j_begin + lj, kin, ibs0,
-                het_i + het_j - 2 * both_het, ibs2, a.max_results, a.results,
-                a.result_index, a.result_overflow);
+    uint32_t gi, gj;
+    record_pair(a, stored_row(a, li), stored_col(a, lj), &gi, &gj);
+    emit_result(gi, gj, kin, ibs0, het_i + het_j - 2 * both_het, ibs2, a.max_results,
+                a.results, a.result_index, a.result_overflow);
   }
 }
 
@@ -240,7 +280,7 @@ __device__ __forceinline__ bool kinship_may_pass_num(float num, float min_hets,
 // opp = (hom_hom - q) / 2 from the recounted hom_hom.  Must be called by all 64
 // lanes.
 __device__ __forceinline__ void lean_epilogue_pair_n4(
-    const EmitCtx &a, bool valid, uint32_t li, uint32_t lj, uint32_t het_i,
+    const EmitCtxP &a, bool valid, uint32_t li, uint32_t lj, uint32_t het_i,
     uint32_t het_j, uint32_t dd, int32_t q, uint32_t lane) {
   const uint32_t min_hets = het_i < het_j ? het_i : het_j;
   const int32_t num = (int32_t)(het_i + het_j) - 2 * (int32_t)dd + 2 * q;
@@ -253,18 +293,18 @@ __device__ __forceinline__ void lean_epilogue_pair_n4(
     pending &= pending - 1;
     const uint32_t p_li = __builtin_amdgcn_readlane(li, src);
     const uint32_t p_lj = __builtin_amdgcn_readlane(lj, src);
-    const uint32_t off_j = a.diag ? p_lj : a.num_rows + p_lj;
-    const uint32_t sum =
-        wave_hom_hom_count(a.bits, a.words_per_sample, p_li, off_j, lane);
+    const uint32_t sum = wave_hom_hom_count(a.bits, a.words_per_sample, stored_row(a, p_li),
+                                            stored_col(a, p_lj), lane);
     if ((int)lane == src) hom_hom = sum;
   }
   if (emit) {
     const uint32_t both_het = het_i + het_j - dd + hom_hom;
     const uint32_t opp = (uint32_t)((int32_t)hom_hom - q) >> 1;
     const uint32_t ibs2 = hom_hom - opp + both_het;
-    emit_result(a.i_begin + li, a.j_begin + lj, kin, opp,
-                het_i + het_j - 2 * both_het, ibs2, a.max_results, a.results,
-                a.result_index, a.result_overflow);
+    uint32_t gi, gj;
+    record_pair(a, stored_row(a, li), stored_col(a, lj), &gi, &gj);
+    emit_result(gi, gj, kin, opp, het_i + het_j - 2 * both_het, ibs2, a.max_results,
+                a.results, a.result_index, a.result_overflow);
   }
 }
 
@@ -275,6 +315,18 @@ __device__ __forceinline__ void full_epilogue_pair(
   if (!valid) return;
   const uint32_t conc = hom_hom - opp;
   const uint32_t shared = het_i + het_j - both_het + hom_hom;
+  // (a sorted layout: the pair's stored samples; in a diagonal block the smaller one is
+  //  "i", and het_i / het_j follow it)
+  uint32_t si = li, sj = lj;  // row / column index within the block
+  if (a.perm != nullptr) {
+    si = a.perm[li];
+    sj = a.perm[a.geo.col_base + lj];
+    if (!a.geo.diag) sj -= a.geo.num_rows;
+    if (a.geo.diag && si > sj) {
+      const uint32_t t = si; si = sj; sj = t;
+      const uint32_t h = het_i; het_i = het_j; het_j = h;
+    }
+  }
   if (a.dense_counts != nullptr) {
     cuking_counts c;
     c.het_i = het_i;
@@ -283,13 +335,13 @@ __device__ __forceinline__ void full_epilogue_pair(
     c.opposing_hom = opp;
     c.concordant_hom = conc;
     c.shared = shared;
-    a.dense_counts[(uint64_t)li * a.geo.num_cols + lj] = c;
+    a.dense_counts[(uint64_t)si * a.geo.num_cols + sj] = c;
     return;
   }
   const float kin = king_kinship(het_i, het_j, both_het, opp);
   if (kin > a.kin_threshold) {
     const uint32_t ibs0 = opp, ibs2 = conc + both_het;
-    emit_result(a.i_begin + li, a.j_begin + lj, kin, ibs0, shared - ibs0 - ibs2,
+    emit_result(a.i_begin + si, a.j_begin + sj, kin, ibs0, shared - ibs0 - ibs2,
                 ibs2, a.max_results, a.results, a.result_index,
                 a.result_overflow);
   }

@@ -591,7 +591,17 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
     uint32_t *const ck_words = reinterpret_cast<uint32_t *>(ck_cols + kT);  // one per wavefront
     {
       const float *const pu = a.prefix_u + (size_t)(forecast ? 0u : entry1) * s_stride;
-      const float t = 2.f - 4.f * a.kin_threshold;
+      // (the forecast counts the pairs that WILL be candidates from an eighth of the sites:
+      //  the bound of an unrelated pair scatters sqrt(8) times as widely there as at the
+      //  end, 1 / sqrt(sites).  A quadrant goes dense from 2.3 % candidates on -- pairs two
+      //  standard deviations out --, so the prefix count matches the final one at that
+      //  point when the prefix is tested against a threshold 2 (sqrt(8) - 1) standard
+      //  deviations higher; tested against the threshold itself it called cohorts dense that
+      //  the list handles at a third of the cost: 7 % missing calls at the default threshold,
+      //  profiles/r04_missing_curve.txt)
+      const float thr_f = forecast ? a.kin_threshold + 3.66f * rsqrtf(256.f * (float)all_steps)
+                                   : a.kin_threshold;
+      const float t = 2.f - 4.f * thr_f;
       const size_t ir = (size_t)tr * kT + threadIdx.x;
       const size_t ic = (size_t)a.geo.col_base + (size_t)tc * kT + threadIdx.x;
       ck_rows[threadIdx.x] = make_float2(pu[ir], scale * fmaf(t, a.sample_stats[ir].y, 8.f));
@@ -615,7 +625,12 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-    if (lane == 0) ck_words[wave] = forecast ? (cnt > a.quadrant_cap ? 1u : 0u) : (cnt != 0 ? 1u : 0u);
+    // (forecast: twice the cap -- the pairs of a quadrant share their samples, so the count
+    //  of a quadrant scatters more widely than independent pairs would; at 7 % missing calls
+    //  and the default threshold a sixth of the tiles left with the cap itself, for a launch
+    //  the candidate list handles in half the time)
+    if (lane == 0)
+      ck_words[wave] = forecast ? (cnt > 2 * a.quadrant_cap ? 1u : 0u) : (cnt != 0 ? 1u : 0u);
     __syncthreads();
     uint32_t found = ck_words[0] + ck_words[1] + ck_words[2] + ck_words[3];
     found = __builtin_amdgcn_readfirstlane(found);
@@ -871,8 +886,11 @@ __global__ __launch_bounds__(256) void king_refine_kernel(const TiledArgs a) {
   for (uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6); p < count; p += stride) {
     const uint2 e = a.cand_list[p];
     if (e.x == kNoPair) continue;  // (uniform: a slot of a quadrant that went dense)
-    const uint32_t off_j = a.geo.diag ? e.y : a.geo.num_rows + e.y;
-    const uint64_t *het_i_w = a.bits + (uint64_t)e.x * a.words_per_sample;
+    // (plane indices of the pair -> the stored samples behind them, king_common.h `perm`)
+    const uint32_t off_i = a.perm != nullptr ? a.perm[e.x] : e.x;
+    const uint32_t off_j = a.perm != nullptr ? a.perm[a.geo.col_base + e.y]
+                                             : (a.geo.diag ? e.y : a.geo.num_rows + e.y);
+    const uint64_t *het_i_w = a.bits + (uint64_t)off_i * a.words_per_sample;
     const uint64_t *alt_i_w = het_i_w + n;
     const uint64_t *het_j_w = a.bits + (uint64_t)off_j * a.words_per_sample;
     const uint64_t *alt_j_w = het_j_w + n;
@@ -917,7 +935,9 @@ __global__ __launch_bounds__(256) void king_refine_kernel(const TiledArgs a) {
       const float kin = king_kinship(s_het_i, s_het_j, s_both, s_opp);
       if (kin > a.kin_threshold) {
         const uint32_t ibs0 = s_opp, ibs2 = s_conc + s_both;
-        emit_result(a.i_begin + e.x, a.j_begin + e.y, kin, ibs0, s_shared - ibs0 - ibs2, ibs2,
+        const uint32_t gi = a.i_begin + off_i;
+        const uint32_t gj = a.geo.diag ? a.j_begin + off_j : a.j_begin + (off_j - a.geo.num_rows);
+        emit_result(gi < gj ? gi : gj, gi < gj ? gj : gi, kin, ibs0, s_shared - ibs0 - ibs2, ibs2,
                     a.max_results, a.results, a.result_index, a.result_overflow);
       }
     }
@@ -934,8 +954,10 @@ hipError_t launch_sample_stats(const uint64_t *d_bit_sets, uint32_t words_per_sa
                                uint32_t s_end, hipStream_t stream) {
   if (s_end > geo.s_stride) s_end = geo.s_stride;
   if (s_begin >= s_end) return hipSuccess;
-  float2 *stats = const_cast<float2 *>(plane_stats(d_planes, geo));
-  float *prefix = const_cast<float *>(plane_prefix_u(d_planes, geo));
+  // (in stored order, into the arrays the sample order is built from: king_sort.hip puts
+  //  them into plane order)
+  float2 *stats = plane_tmp_stats(d_planes, geo);
+  float *prefix = plane_tmp_prefix(d_planes, geo);
   unsigned long long *sums = const_cast<unsigned long long *>(plane_cohort_sums(d_planes, geo));
   uint32_t *steps = const_cast<uint32_t *>(plane_check_steps(d_planes, geo));
   CheckWords cw;
@@ -1043,6 +1065,16 @@ hipError_t launch_filter(const TiledArgs &args, uint64_t num_tiles, hipStream_t 
     king_refine_kernel<<<dim3(wgs * 4), dim3(256), 0, stream>>>(a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (a.codes_ready != nullptr) {
+      // Lazy codes (king_common.h): the four-product kernel's layout for the whole block,
+      // if this chunk handed anything to that kernel and the codes are not there yet.
+      e = launch_prepare_nibbles(true, false, a.bits, a.words_per_sample, a.geo,
+                                 const_cast<uint4 *>(a.planes), a.perm, 0, 0xFFFFFFFFu,
+                                 a.filter_ctrl, a.codes_ready, stream);
+      if (e != hipSuccess) return e;
+      e = launch_mark_codes_ready(a.filter_ctrl, a.codes_ready, stream);
+      if (e != hipSuccess) return e;
+    }
     TiledArgs d = a;
     d.tile_list = a.dense_list;
     d.tile_list_count = a.filter_ctrl + kCtrlDense;

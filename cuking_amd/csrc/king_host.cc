@@ -7,12 +7,14 @@
 #include "king_host.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <string>
 #include <tuple>
 #include <vector>
 
+#include "../host/schedule.h"
 #include "king_submatrix.h"
 
 using namespace cuking;
@@ -262,6 +264,63 @@ cuking_status cuking_narrow_triples(const cuking_submatrix *sm, uint32_t words_p
   }
   *num_out = w;
   return CUKING_OK;
+}
+
+// ---- schedules of a block over the GPUs of a node (host/schedule.h) ----------
+void cuking_schedule_tile_partition(uint64_t num_tiles, uint32_t world, uint64_t *out) {
+  if (world == 0 || out == nullptr) return;
+  const auto parts = cuking_host::TilePartition(num_tiles, world);
+  for (uint32_t r = 0; r < world; ++r) {
+    out[2 * r] = parts[r].begin;
+    out[2 * r + 1] = parts[r].end;
+  }
+}
+
+cuking_status cuking_schedule_weighted_tile_partition(uint64_t num_tiles, const double *weights,
+                                                      uint32_t world, uint64_t *out) {
+  if (world == 0 || weights == nullptr || out == nullptr)
+    return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "null argument");
+  std::vector<double> w(weights, weights + world);
+  for (double x : w)
+    if (!(x > 0) || !std::isfinite(x))
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "weights must be positive");
+  const auto parts = cuking_host::WeightedTilePartition(num_tiles, w);
+  for (uint32_t r = 0; r < world; ++r) {
+    out[2 * r] = parts[r].begin;
+    out[2 * r + 1] = parts[r].end;
+  }
+  return CUKING_OK;
+}
+
+uint64_t cuking_schedule_calibration_tiles(uint64_t num_tiles, uint32_t world) {
+  return cuking_host::CalibrationTiles(num_tiles, world);
+}
+
+uint32_t cuking_schedule_chunk_ranges(uint32_t num_samples, uint32_t tile, uint32_t num_chunks,
+                                      uint32_t *out) {
+  if (tile == 0 || out == nullptr) return 0;
+  const auto chunks = cuking_host::ChunkRanges(num_samples, tile, num_chunks);
+  for (size_t c = 0; c < chunks.size(); ++c) {
+    out[2 * c] = chunks[c].begin;
+    out[2 * c + 1] = chunks[c].end;
+  }
+  return (uint32_t)chunks.size();
+}
+
+uint32_t cuking_schedule_staged_steps(uint32_t num_samples, uint32_t tile, uint32_t world,
+                                      uint32_t rank, uint32_t num_chunks, uint32_t *out) {
+  if (tile == 0 || world == 0 || rank >= world || out == nullptr) return 0;
+  const auto steps = cuking_host::StagedSchedule(num_samples, tile, world, rank, num_chunks);
+  for (size_t k = 0; k < steps.size(); ++k) {
+    uint32_t *o = out + 6 * k;
+    o[0] = steps[k].chunk.begin;
+    o[1] = steps[k].chunk.end;
+    o[2] = steps[k].has_rect ? 1u : 0u;
+    o[3] = steps[k].row_begin;
+    o[4] = steps[k].row_end;
+    o[5] = steps[k].row_step;
+  }
+  return (uint32_t)steps.size();
 }
 
 void cuking_sort_results(cuking_result *results, size_t num_results) {

@@ -165,13 +165,20 @@ __device__ __forceinline__ uint32_t spread8(uint32_t b) {
 #endif
 constexpr int kNibWords = CUKING_NIB_WORDS;
 
-// T2: the filter kernel's two-bit layout as well (king_common.h, kLayoutNibbleStats).
-template <bool T2>
+// CODES: the fp4 codes and the het-only copy; T2: the filter kernel's two-bit layout
+// (king_common.h, kLayoutNibbleStats).  `perm` (or nullptr): which stored sample sits at
+// a plane sample (king_common.h).  `gate` (or nullptr): the filter's control words -- the
+// launch converts only if a quadrant went dense or a tile left for the exact kernel, and
+// the codes are not there yet (*ready).
+template <bool CODES, bool T2>
 __global__ __launch_bounds__(256) void prepare_nibbles_kernel(
     const uint64_t *__restrict__ bits, uint32_t words_per_sample,
-    PlaneGeometry geo, uint4 *__restrict__ planes, uint32_t s_tile_begin) {
+    PlaneGeometry geo, uint4 *__restrict__ planes, uint32_t s_tile_begin,
+    const uint32_t *__restrict__ perm, const uint32_t *__restrict__ gate,
+    const uint32_t *__restrict__ ready) {
   __shared__ uint64_t het_lds[kPrepSamples][kNibWords + 1];
   __shared__ uint64_t hom_lds[kPrepSamples][kNibWords + 1];
+  if (gate != nullptr && ((gate[kCtrlGate] | gate[kCtrlDense]) == 0 || *ready != 0)) return;
 
   const uint32_t plane_words = words_per_sample / 2;
   const uint32_t s0 = (s_tile_begin + blockIdx.x) * kPrepSamples;
@@ -187,7 +194,9 @@ __global__ __launch_bounds__(256) void prepare_nibbles_kernel(
     const uint32_t s = idx / (kNibWords / 2), w = (idx % (kNibWords / 2)) * 2;
     const uint32_t ps = s0 + s;  // plane sample index
     uint32_t src = 0xFFFFFFFFu;  // which stored sample of the reference bitset, if any
-    if (geo.diag || ps < geo.rows_padded) {
+    if (perm != nullptr) {
+      if (ps < geo.s_stride) src = perm[ps];
+    } else if (geo.diag || ps < geo.rows_padded) {
       if (ps < geo.num_rows) src = ps;
     } else {
       const uint32_t c = ps - geo.col_base;
@@ -217,6 +226,7 @@ __global__ __launch_bounds__(256) void prepare_nibbles_kernel(
   }
   __syncthreads();
 
+  if constexpr (CODES) {
 #pragma unroll
   for (int it = 0; it < kPrepSamples * kNibWords * 2 / 256; ++it) {
     const uint32_t idx = it * 256 + threadIdx.x;
@@ -252,6 +262,7 @@ __global__ __launch_bounds__(256) void prepare_nibbles_kernel(
     hetq[(uint64_t)q * geo.s_stride + s0 + s] =
         make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
   }
+  }  // CODES
   if constexpr (T2) {
     // One unit = one 64-bit word of the reference planes: its low 32 sites in
     // bits 2-3 of the nibbles, its high 32 sites in bits 0-1; per site (hom-alt,
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(256) void prepare_nibbles_kernel(
 // PHASED: a workgroup with two waves per SIMD runs every k-step as a logic
 // phase (v_and / v_bitop3 into temporaries) followed by a popcount phase
 // (v_bcnt), with one s_barrier in front of each logic phase.  Measured on
-// gfx950 (tools/micro/valu_phase.hip, profiles/r01_valu_microbench.txt): a
+// gfx950 (tools/micro/valu_phase.hip, archive/profiles/r01_valu_microbench.txt): a
 // wave issues at most one VALU instruction per 4 cycles; a full-rate
 // instruction leaves half of that slot to ANOTHER wave's full-rate
 // instruction, a half-rate v_bcnt takes all of it.  Unsynchronised waves mix
@@ -819,30 +830,51 @@ hipError_t launch_prepare_planes(uint32_t layout, const uint64_t *d_bit_sets,
   const dim3 grid(s_tile_end - s_tile_begin,
                   (geo.k_words + 2 * block_words - 1) / (2 * block_words));
   if (grid.y == 0) return hipSuccess;
-  if (layout == kLayoutNibbleStats && s_tile_begin == 0) {
-    // a conversion that starts at plane sample 0 starts the cohort's sums afresh
-    // (staged preparation: the later sample ranges add to them)
-    hipError_t e0 = hipMemsetAsync(
-        const_cast<unsigned long long *>(plane_cohort_sums(d_planes, geo)), 0, 64, stream);
-    if (e0 != hipSuccess) return e0;
-  }
   if (layout == kLayoutQuad)
     prepare_quads_kernel<<<grid, dim3(256), 0, stream>>>(
         d_bit_sets, words_per_sample, geo, d_planes, s_tile_begin);
   else if (layout == kLayoutNibbleStats)
-    prepare_nibbles_kernel<true><<<grid, dim3(256), 0, stream>>>(
-        d_bit_sets, words_per_sample, geo, d_planes, s_tile_begin);
+    return hipErrorInvalidValue;  // (king_abi.hip prepares that layout step by step)
   else if (nibble)
-    prepare_nibbles_kernel<false><<<grid, dim3(256), 0, stream>>>(
-        d_bit_sets, words_per_sample, geo, d_planes, s_tile_begin);
+    prepare_nibbles_kernel<true, false><<<grid, dim3(256), 0, stream>>>(
+        d_bit_sets, words_per_sample, geo, d_planes, s_tile_begin, nullptr, nullptr, nullptr);
   else
     prepare_planes_kernel<<<grid, dim3(256), 0, stream>>>(
         d_bit_sets, words_per_sample, geo, d_planes, s_tile_begin);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess && layout == kLayoutNibbleStats)
-    e = launch_sample_stats(d_bit_sets, words_per_sample, geo, d_planes,
-                            s_tile_begin * kPrepSamples, s_tile_end * kPrepSamples, stream);
-  return e;
+  return hipGetLastError();
+}
+
+hipError_t launch_prepare_nibbles(bool codes, bool t2, const uint64_t *d_bit_sets,
+                                  uint32_t words_per_sample, const PlaneGeometry &geo,
+                                  uint4 *d_planes, const uint32_t *perm, uint32_t s_tile_begin,
+                                  uint32_t s_tile_end, const uint32_t *gate,
+                                  const uint32_t *ready, hipStream_t stream) {
+  const uint32_t all = (geo.s_stride + kPrepSamples - 1) / kPrepSamples;
+  if (s_tile_end > all) s_tile_end = all;
+  if (s_tile_begin >= s_tile_end || (!codes && !t2)) return hipSuccess;
+  const dim3 grid(s_tile_end - s_tile_begin, (geo.k_words + 2 * kNibWords - 1) / (2 * kNibWords));
+  if (grid.y == 0) return hipSuccess;
+  if (codes && t2)
+    prepare_nibbles_kernel<true, true><<<grid, dim3(256), 0, stream>>>(
+        d_bit_sets, words_per_sample, geo, d_planes, s_tile_begin, perm, gate, ready);
+  else if (codes)
+    prepare_nibbles_kernel<true, false><<<grid, dim3(256), 0, stream>>>(
+        d_bit_sets, words_per_sample, geo, d_planes, s_tile_begin, perm, gate, ready);
+  else
+    prepare_nibbles_kernel<false, true><<<grid, dim3(256), 0, stream>>>(
+        d_bit_sets, words_per_sample, geo, d_planes, s_tile_begin, perm, gate, ready);
+  return hipGetLastError();
+}
+
+namespace {
+__global__ void mark_codes_ready_kernel(const uint32_t *gate, uint32_t *ready) {
+  if ((gate[kCtrlGate] | gate[kCtrlDense]) != 0) *ready = 1;
+}
+}  // namespace
+
+hipError_t launch_mark_codes_ready(const uint32_t *gate, uint32_t *ready, hipStream_t stream) {
+  mark_codes_ready_kernel<<<dim3(1), dim3(1), 0, stream>>>(gate, ready);
+  return hipGetLastError();
 }
 
 hipError_t launch_stream(const cuking_submatrix &sm, uint32_t words_per_sample,

@@ -30,7 +30,7 @@
 // and expanded four times (f = 0..3): 80 MFMAs per k-step and wavefront.  The
 // planes come from the quad layout (king_common.h) by LDS-DMA, 16 KiB per
 // k-step, kStages stages deep.  DESIGN.md 4.1 has the measurements behind the
-// choices; profiles/r01_mfma_microbench.txt the raw numbers.
+// choices; archive/profiles/r01_mfma_microbench.txt the raw numbers.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -77,7 +77,7 @@ constexpr bool kPairedSync = CUKING_MFMA_PAIRED != 0 && kStages == 6;
 // even, 8 or 10.  10 x 16 KiB is the CU's whole LDS and puts 5.5 instead of 3.5
 // k-steps between a request and the hand-over that needs it: configs[2] 593 ->
 // 590 ms, 40k x 100k 95.2 -> 94.7 ms, configs[1] (bitset in the Infinity Cache) equal
-// (tools/experiments/exp25.sh).
+// (archive/experiments/exp25.sh).
 #define CUKING_MFMA_PAIRED_STAGES 10
 #endif
 constexpr int kStagesPaired = CUKING_MFMA_PAIRED_STAGES;
@@ -141,7 +141,7 @@ __device__ __attribute__((noinline)) void lean_epilogue_call(
 }
 
 __device__ __attribute__((noinline)) void lean_epilogue_call_n4(
-    const EmitCtx c, bool valid, uint32_t li, uint32_t lj, uint32_t het_i,
+    const EmitCtxP c, bool valid, uint32_t li, uint32_t lj, uint32_t het_i,
     uint32_t het_j, uint32_t dd, int32_t q, uint32_t lane) {
   lean_epilogue_pair_n4(c, valid, li, lj, het_i, het_j, dd, q, lane);
 }
@@ -156,8 +156,9 @@ __device__ __attribute__((noinline)) void lean_epilogue_call_n4(
 // 11 ms per 10^6 records at configs[1] when most pairs pass.
 // ... and the record itself (cuking.cu:297-313), out of line as well: the kernel
 // around it has no registers to spare for 64 inlined copies.
+template <class Ctx>
 __device__ __attribute__((noinline)) void full_store_call(
-    const EmitCtx c, uint32_t slot, uint32_t li, uint32_t lj, uint32_t het_i, uint32_t het_j,
+    const Ctx c, uint32_t slot, uint32_t li, uint32_t lj, uint32_t het_i, uint32_t het_j,
     uint32_t both_het, uint32_t opp, uint32_t hom_hom) {
   if (slot >= c.max_results) {
     atomicMax(c.result_overflow, 1u);
@@ -166,8 +167,7 @@ __device__ __attribute__((noinline)) void full_store_call(
   const uint32_t ibs2 = hom_hom - opp + both_het;
   const uint32_t shared = het_i + het_j - both_het + hom_hom;
   cuking_result rec;
-  rec.sample_i = c.i_begin + li;
-  rec.sample_j = c.j_begin + lj;
+  record_pair(c, stored_row(c, li), stored_col(c, lj), &rec.sample_i, &rec.sample_j);
   rec.kin = king_kinship(het_i, het_j, both_het, opp);
   rec.ibs0 = opp;
   rec.ibs1 = shared - opp - ibs2;
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     // XCDs (XCD x takes patches x, x + 8, ...); otherwise one contiguous chunk
     // of xcd_chunk tiles per XCD.
 #ifndef CUKING_XCD_XOR
-#define CUKING_XCD_XOR 0  // (experiment: which patches an XCD takes, profiles/r02_tail.txt)
+#define CUKING_XCD_XOR 0  // (experiment: which patches an XCD takes, archive/profiles/r02_tail.txt)
 #endif
     bid = a.xcd_chunk == 1 ? (((j >> 5) * 8 + (x ^ CUKING_XCD_XOR)) << 5) + (j & 31)
                            : x * a.xcd_chunk + j;
@@ -717,8 +717,8 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
     [[maybe_unused]] int stamp_row = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
 #endif
-    // Where a k-step's LDS reads of the NEXT k-step go (tools/experiments/exp14.sh, one box,
-    // profiles/r02_mfma_stamps.txt): 0 = all eight in front of phase f = 3 (round
+    // Where a k-step's LDS reads of the NEXT k-step go (archive/experiments/exp14.sh, one box,
+    // archive/profiles/r02_mfma_stamps.txt): 0 = all eight in front of phase f = 3 (round
     // 1), 1 = in front of phase f = 2, 2 = phase f = 2, one behind each of its
     // first eight MFMAs (default), 3 = one per two MFMAs.
 #ifndef CUKING_RD_MODE
@@ -1342,7 +1342,10 @@ __global__ __launch_bounds__(256, 1) void king_mfma_kernel(const TiledArgs a) {
   }
   // --- epilogue: kinship, threshold, append (cuking.cu:284-313).  C layout of
   // the 32 x 32 MFMA: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
-  const EmitCtx emit_ctx = make_emit_ctx(a);
+  const auto emit_ctx = [&]() {
+    if constexpr (N4) return make_emit_ctx_p(a);
+    else return make_emit_ctx(a);
+  }();
   // The five sums of pair (bi, bj, r) as integers.  Five products: they are the
   // accumulators (hom_hom parked, `parked`).  Four products: hi / 2, hj / 2, dd,
   // 4 q (and hom_hom in hh5) are, and bh = hi + hj - dd + hom_hom,
@@ -1815,11 +1818,11 @@ hipError_t launch_mfma(bool full, bool nibble, const TiledArgs &args, uint64_t n
   // CUKING_SPLIT_ROUNDS tiles per CU: 36 tiles 0.57 -> 0.25 ms, 300 tiles
   // 1.26 -> 0.91 ms, 820 tiles 2.40 -> 2.15 ms; configs[1] (3160 tiles = 12.3
   // rounds, the dispatcher's back-filling does not hide the 13th: time follows
-  // ceil(rounds), tools/experiments/exp15.sh) 6.93 -> 6.75 ms and 7.12 -> 6.84 ms on two
+  // ceil(rounds), archive/experiments/exp15.sh) 6.93 -> 6.75 ms and 7.12 -> 6.84 ms on two
   // boxes.  A piece costs ~30 us per tile it touches (slab, ticket) and the
   // pieces end as far apart as the whole tiles before them did (~0.3 ms after
   // 12 rounds), which is what is left of the ideal 0.66 x 0.53 ms
-  // (profiles/r02_tail.txt); beyond 64 rounds the gain is under 1 %.
+  // (archive/profiles/r02_tail.txt); beyond 64 rounds the gain is under 1 %.
   const uint32_t wgs = args.split_wgs;
   const uint32_t tile_steps = args.geo.k_words / 8;
   uint64_t whole = num_tiles;

@@ -80,15 +80,20 @@ def agree_on_status(error: Optional[BaseException] = None, group=None, device=No
         raise RemoteRankError(f"rank(s) {failed} failed; rank {rank} stops with them")
 
 
+# The schedules themselves -- tile partitions, broadcast chunks, the staged row deal -- are
+# ONE implementation, cuking_amd/host/schedule.h, shared with the C++ host `cuking
+# --num_gpus=N` and reached from here through the C ABI (cuking_schedule_*).
+def _lib():
+    from . import _lib as binding
+    return binding.load()
+
+
 def tile_partition(num_tiles: int, world_size: int) -> List[Tuple[int, int]]:
     """Contiguous ranges, sizes differing by at most one tile."""
-    base, extra = divmod(num_tiles, world_size)
-    out, begin = [], 0
-    for r in range(world_size):
-        end = begin + base + (1 if r < extra else 0)
-        out.append((begin, end))
-        begin = end
-    return out
+    import ctypes as C
+    out = (C.c_uint64 * (2 * world_size))()
+    _lib().cuking_schedule_tile_partition(num_tiles, world_size, out)
+    return [(int(out[2 * r]), int(out[2 * r + 1])) for r in range(world_size)]
 
 
 def weighted_tile_partition(num_tiles: int, weights) -> List[Tuple[int, int]]:
@@ -96,17 +101,15 @@ def weighted_tile_partition(num_tiles: int, weights) -> List[Tuple[int, int]]:
     tiles per millisecond): the GPUs of one node differ by several percent in the
     clock they sustain under this load, and with equal ranges the slowest one
     sets the pace.  Exact cover of [0, num_tiles), monotone, every weight > 0."""
+    import ctypes as C
     w = [float(x) for x in weights]
-    if not w or min(w) <= 0.0:
+    if not w or not all(x > 0.0 and x == x and x != float("inf") for x in w):
         raise ValueError("weights must be positive")
-    total = sum(w)
-    out, begin, acc = [], 0, 0.0
-    for r, x in enumerate(w):
-        acc += x
-        end = num_tiles if r == len(w) - 1 else min(num_tiles, max(begin, round(num_tiles * acc / total)))
-        out.append((begin, end))
-        begin = end
-    return out
+    arr = (C.c_double * len(w))(*w)
+    out = (C.c_uint64 * (2 * len(w)))()
+    if _lib().cuking_schedule_weighted_tile_partition(num_tiles, arr, len(w), out) != 0:
+        raise ValueError("weights must be positive")
+    return [(int(out[2 * r]), int(out[2 * r + 1])) for r in range(len(w))]
 
 
 def broadcast_bitset(bit_sets, src: int = 0, group=None) -> None:
@@ -342,15 +345,11 @@ def all_pairs_king(compute_tiles: Callable, num_tiles: int, bit_sets,
 # ---------------------------------------------------------------------------
 def chunk_ranges(num_samples: int, tile: int, num_chunks: int) -> List[Tuple[int, int]]:
     """Ascending, tile-aligned sample chunks covering [0, num_samples)."""
-    tiles = (num_samples + tile - 1) // tile
-    num_chunks = max(1, min(num_chunks, tiles))
-    out = []
-    for c in range(num_chunks):
-        b = tiles * c // num_chunks * tile
-        e = min(tiles * (c + 1) // num_chunks * tile, num_samples)
-        if e > b:
-            out.append((b, e))
-    return out
+    import ctypes as C
+    cap = max(1, num_chunks)
+    out = (C.c_uint32 * (2 * cap))()
+    n = _lib().cuking_schedule_chunk_ranges(num_samples, tile, num_chunks, out)
+    return [(int(out[2 * c]), int(out[2 * c + 1])) for c in range(n)]
 
 
 def rank_tile_share(num_tile_rows: int, world: int, rank: int) -> float:
@@ -368,13 +367,14 @@ def staged_schedule(num_samples: int, tile: int, world: int, rank: int,
     col_end)) in samples: the rank's tile rows (rank, rank + world, ...) that lie
     below chunk_end x the chunk's columns.  A pair (i < j) is evaluated with the
     chunk that holds j, by the rank that owns i's tile row."""
+    import ctypes as C
+    cap = max(1, num_chunks)
+    out = (C.c_uint32 * (6 * cap))()
+    n = _lib().cuking_schedule_staged_steps(num_samples, tile, world, rank, num_chunks, out)
     steps = []
-    first_row = rank * tile
-    for c0, c1 in chunk_ranges(num_samples, tile, num_chunks):
-        if first_row >= c1:
-            steps.append(((c0, c1), None))
-        else:
-            steps.append(((c0, c1), ((first_row, c1, world * tile), (c0, c1))))
+    for k in range(n):
+        c0, c1, has_rect, r0, r1, step = (int(out[6 * k + j]) for j in range(6))
+        steps.append(((c0, c1), ((r0, r1, step), (c0, c1)) if has_rect else None))
     return steps
 
 

@@ -417,10 +417,13 @@ Status Run(const Flags &flags) {
     // device pack is ahead (1e9 triples: +37 %); below that its set-up is not
     // amortised (1e8 triples: 0.27 s against 0.20 s), and beyond ~32 threads the
     // host's cores outrun one GPU's atomic units.
+    // (the reader threads that can run at once: the flag's default is the reference's 36,
+    //  cuking.cu:36, whatever the box -- a GPU's share of a node is 16 hardware threads)
     size_t input_bytes = 0;
     for (const auto &f : input_files) input_bytes += f.second;
-    pack_mode = (flags.num_reader_threads <= 32 && input_bytes >= (size_t(1) << 30)) ? "device"
-                                                                                      : "host";
+    const size_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t running = std::min(flags.num_reader_threads, hw);
+    pack_mode = (running <= 32 && input_bytes >= (size_t(1) << 30)) ? "device" : "host";
   }
   const bool pack_on_device = (pack_mode == "device" || synthetic) && !dump_only;
 

@@ -54,8 +54,9 @@ std::string Usage() {
          "filter + exact recount; 6 = four products for every pair: the choice when more than "
          "~10 % of the calls are missing or the threshold sits inside the noise of unrelated "
          "pairs; same records either way)\n"
-         "  --pack=host|device|auto  where triples are packed (default auto: device when at "
-         "most 32 reader threads feed the GPU)\n"
+         "  --pack=host|device|auto  where triples are packed (default auto: device for inputs "
+         "of 1 GiB of Parquet or more when at most 32 reader threads can run at once -- the "
+         "smaller of --num_reader_threads and the hardware threads this process sees)\n"
          "  --decode=table|stream|auto  table: decode a whole table (or row group), then pack "
          "it; stream: pack batches of triples as they are decoded (no column-sized buffers); "
          "default auto: stream for the host pack, table for the device pack\n"

@@ -26,8 +26,8 @@ struct Flags {
   int device = 0;                       // HIP device index
   std::string kernel = "tiled";         // tiled | stream
   int variant = -1;                     // tiled kernel variant (library option "variant"); -1: the default
-  std::string pack = "auto";            // host | device | auto (device when the
-                                        // reader threads per GPU are few, cuking_main.cc)
+  std::string pack = "auto";            // host | device | auto (device for large inputs when
+                                        // few reader threads can run at once, cuking_main.cc)
   std::string decode = "auto";          // table: a whole table (or row group) decoded, then
                                         // packed; stream: batches of triples packed as they
                                         // are decoded (parquet_io.h StreamTriples); auto:

@@ -293,6 +293,26 @@ cuking_status cuking_compute_king_tiles(
     float kin_threshold, uint32_t max_results, cuking_result *d_results,
     uint32_t *d_result_index, uint32_t *d_result_overflow, void *stream);
 
+/* The schedules of one block over the GPUs of a node (host arithmetic only; the
+ * reference fans shards out over VMs instead: cloud_batch_submit.py:45,73).  ONE
+ * implementation (cuking_amd/host/schedule.h) behind the C++ host `cuking --num_gpus=N`
+ * and, through these entry points, the Python driver cuking_amd/dist.py.
+ *   tile partition   contiguous ranges of the tile enumeration, equal or in proportion
+ *                    to per-rank weights: out[2 r], out[2 r + 1] = rank r's [begin, end)
+ *   chunk ranges     ascending tile-aligned sample chunks of the staged broadcast:
+ *                    out[2 c], out[2 c + 1]; returns the number of chunks (<= num_chunks)
+ *   staged steps     what rank `rank` does per chunk (tile rows dealt round-robin): six
+ *                    words per chunk -- chunk begin, chunk end, has_rect, row begin, row
+ *                    end, row step (samples); returns the number of chunks */
+void cuking_schedule_tile_partition(uint64_t num_tiles, uint32_t world, uint64_t *out);
+cuking_status cuking_schedule_weighted_tile_partition(uint64_t num_tiles, const double *weights,
+                                                      uint32_t world, uint64_t *out);
+uint64_t cuking_schedule_calibration_tiles(uint64_t num_tiles, uint32_t world);
+uint32_t cuking_schedule_chunk_ranges(uint32_t num_samples, uint32_t tile, uint32_t num_chunks,
+                                      uint32_t *out);
+uint32_t cuking_schedule_staged_steps(uint32_t num_samples, uint32_t tile, uint32_t world,
+                                      uint32_t rank, uint32_t num_chunks, uint32_t *out);
+
 /* Staged form of the same operator for a DIAGONAL block (rows == columns),
  * used when the bitset arrives in pieces (e.g. a chunked RCCL broadcast):
  * cuking_prepare_samples() converts samples [sample_begin, sample_end) (global

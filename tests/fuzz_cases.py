@@ -93,6 +93,9 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
             geno[n - 1] = geno[0]
             if rng.random() < 0.3:
                 geno[1] = -1
+            if rng.random() < 0.3:       # a few low-call-rate samples (the sorted layout's case)
+                who = rng.choice(n, size=max(1, n // 16), replace=False)
+                geno[who] = np.where(rng.random((len(who), m)) < 0.4, -1, geno[who])
         swizzle = int(rng.integers(0, 3))
         band = int(rng.choice([0, 0, 1, 3, 5, 17]))
         wgs = int(rng.choice([0, 256, 256]))
@@ -109,13 +112,15 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
         # rigorous: off / automatic / an entry of the share menu), for bitsets of >= 4 k-steps
         chk0 = int(rng.choice([1, 0, 2, 2]))
         chk1 = int(rng.choice([1, 0, 3, 5, 7, 9]))
+        srt, lazy = int(rng.integers(0, 2)), int(rng.integers(0, 2))   # sorted layout, lazy codes
         if case < first_case:
             continue
         tag = dict(fuzzer="run_general", seed=seed, case=case, n=n, m=m, split_factor=k,
                    shard=shard, thr=thr, kernel=kernel, variant=variant, counts_mode=mode,
                    xcd_swizzle=swizzle, band_rows=band, split_wgs=wgs, reuse_prepared=reuse,
                    filter_quadrant_cap=qcap, filter_cand_cap=ccap, filter_split_min_steps=smin,
-                   filter_check0=chk0, filter_check1=chk1, filter_check_min_steps=4)
+                   filter_check0=chk0, filter_check1=chk1, filter_check_min_steps=4,
+                   filter_sort=srt, filter_lazy_codes=lazy)
         osm = pyoracle.submatrix(n, k, shard)
         bits = pyoracle.bitset_from_genotypes(geno, osm)
         exp, _, _ = pyoracle.compute(osm, bits, thr, threads=8)
@@ -132,6 +137,8 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
         ctx.set_option("filter_check0", chk0)
         ctx.set_option("filter_check1", chk1)
         ctx.set_option("filter_check_min_steps", 4)
+        ctx.set_option("filter_sort", srt)
+        ctx.set_option("filter_lazy_codes", lazy)
         # (a new bitset may land on a recycled pointer: tell the library)
         ctx.set_option("reuse_prepared", reuse)
         ctx.invalidate()
@@ -167,6 +174,8 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
     ctx.set_option("filter_check0", 1)
     ctx.set_option("filter_check1", 1)
     ctx.set_option("filter_check_min_steps", 64)
+    ctx.set_option("filter_sort", 1)
+    ctx.set_option("filter_lazy_codes", 1)
     return ran
 
 

@@ -768,7 +768,7 @@ def test_hundred_million_triples_through_both_packs(tmp_path_factory):
     row groups) through the host pack and the pipelined device pack: same output
     file, the decode handed out per row group (8 files, 16 reader threads), and
     the device pack not slower than the host pack beyond the noise of a shared
-    box (profiles/r02_pack_pipeline.txt: equal at this size, +37 % at 1e9)."""
+    box (archive/profiles/r02_pack_pipeline.txt: equal at this size, +37 % at 1e9)."""
     import sys
     from concurrent.futures import ProcessPoolExecutor
     tools = str(Path(__file__).resolve().parent.parent / "tools")

@@ -1048,7 +1048,8 @@ def test_reserved_workspace_means_no_allocation_and_no_host_wait(oracle):
         assert c.get_option("workspace_allocations") == 0
         c.reserve(sm, wps, streams)
         a0, s0 = c.get_option("workspace_allocations"), c.get_option("host_syncs")
-        assert a0 == 6                      # layout, prefix table, two split slabs, two filter scratch sets
+        # layout, the sample sort's scratch, prefix table, two split slabs, two filter scratch sets
+        assert a0 == 7
         c.reserve(sm, wps, streams)         # idempotent
         assert c.get_option("workspace_allocations") == a0
         results = torch.zeros((len(exp) + 8, 6), dtype=torch.int32, device="cuda:0")
@@ -1302,6 +1303,73 @@ def test_filter_check_points_inside_the_k_loop(ctx, oracle, missing):
         for k, v in defaults.items():
             ctx.set_option(k, v)
         ctx.set_option("counts_mode", -1)
+
+
+def test_filter_sorted_layout_and_lazy_codes(ctx, oracle):
+    """The filter variant's kernel layout holds the samples of a prepared range sorted by
+    their share of missing calls (king_sort.hip), and the four-product kernel's codes are
+    converted only when a launch hands something to that kernel (lazy codes).  A cohort
+    with a few low-call-rate samples at random positions: the oracle's records and counts
+    with the sort on and off and the codes lazy and eager -- whole block, off-diagonal
+    block, tile ranges, staged rectangles, full form, diagnostic counts, thresholds
+    without a bound -- and with the sort the bad samples spoil far fewer quadrants."""
+    from fuzz_cases import _staged
+    select(ctx, "tiled", 7)
+    rng = np.random.default_rng(41)
+    n, m = 1100, 6200
+    geno = random_genotypes(rng, n, m, missing=0.01)
+    bad = rng.choice(n, size=66, replace=False)
+    geno[bad] = np.where(rng.random((66, m)) < 0.4, -1, geno[bad])
+    geno[n - 1], geno[700], geno[1023], geno[bad[0]] = geno[2], geno[130], geno[256], geno[bad[1]]
+    bits = oracle.bitset_from_genotypes(geno)
+    d_bits = ctx.upload_bitset(bits)
+    wps = bits.shape[1]
+    sm = cuking_amd.Submatrix(n)
+    off = cuking_amd.Submatrix(n, 2, 1)
+    idx = list(range(off.i_begin, off.i_end)) + list(range(off.j_begin, off.j_end))
+    sub = np.ascontiguousarray(bits[idx])
+    d_sub = ctx.upload_bitset(sub)
+    dense = {}
+    try:
+        for sort, lazy in ((1, 1), (0, 1), (1, 0), (0, 0)):
+            ctx.set_option("filter_sort", sort)
+            ctx.set_option("filter_lazy_codes", lazy)
+            for reuse in (0, 1):
+                ctx.set_option("reuse_prepared", reuse)
+                ctx.invalidate()
+                for thr, mode in ((0.0884, 0), (0.05, -1), (0.0884, 1), (0.0, -1), (0.7, 0),
+                                  (0.03, 0), (0.0884, 0)):
+                    ctx.set_option("counts_mode", mode)
+                    exp, _, _ = oracle.compute(oracle.submatrix(n), bits, thr, threads=16)
+                    d0 = ctx.get_option("filter_dense_quadrants")
+                    got = ctx.run(sm, wps, d_bits, thr, max_results=1 << 20)
+                    assert got.tobytes() == exp.tobytes(), (sort, lazy, reuse, thr, mode)
+                    if (thr, mode, reuse) == (0.0884, 0, 0):
+                        dense[sort] = ctx.get_option("filter_dense_quadrants") - d0
+                    e2, _, _ = oracle.compute(oracle.submatrix(n, 2, 1), sub, thr, threads=16)
+                    got = ctx.run(off, wps, d_sub, thr, max_results=1 << 20)
+                    assert got.tobytes() == e2.tobytes(), (sort, lazy, reuse, thr, mode, "off-diagonal")
+                    parts = [ctx.run(sm, wps, d_bits, thr, max_results=1 << 20, tile_range=r,
+                                     sort=False) for r in ((0, 4), (4, 9), (9, 15))]
+                    assert cuking_amd.sort_results(np.concatenate(parts)).tobytes() == exp.tobytes(), \
+                        (sort, lazy, reuse, thr, mode, "tile ranges")
+            ctx.set_option("reuse_prepared", 0)
+            ctx.set_option("counts_mode", 0)
+            exp, _, _ = oracle.compute(oracle.submatrix(n), bits, 0.0884, threads=16)
+            ctx.invalidate()
+            got = _staged(ctx, sm, wps, d_bits, 0.0884, len(exp) + 8, n, 3, 2, [1, 2, 3])
+            assert got.tobytes() == exp.tobytes(), (sort, lazy, "staged")
+            ctx.set_option("counts_mode", -1)
+            check_counts(ctx, oracle, sm, bits)
+            check_counts(ctx, oracle, off, sub)
+        # in stored order ~8 of every 128 samples are bad: every quadrant of the 45 with a
+        # pair i < j goes dense; sorted, the 66 bad samples fill the last quadrant row and
+        # column
+        assert dense[0] >= 40 and dense[1] <= 20, dense
+    finally:
+        for k, v in (("filter_sort", 1), ("filter_lazy_codes", 1), ("reuse_prepared", 0),
+                     ("counts_mode", -1)):
+            ctx.set_option(k, v)
 
 
 @pytest.mark.parametrize("missing,thr", [(0.35, 0.05), (0.02, 0.004), (0.03, 0.07), (0.03, 0.085)])

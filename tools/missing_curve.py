@@ -25,6 +25,17 @@ SEED = 20240229
 MAX_RESULTS = 1 << 24
 
 
+def heterogeneous_missing(bits, fraction, k, gen):
+    """`fraction` of the samples (every round(1 / fraction)-th one) get extra missing calls
+    of density 2^-k: the few low-call-rate samples of an ordinary cohort."""
+    n = bits.shape[0]
+    step = max(1, int(round(1.0 / fraction)))
+    who = torch.arange(step // 2, n, step, device=bits.device)
+    out = bits.clone()
+    out[who] = extra_missing(bits[who], k, gen)
+    return out, len(who)
+
+
 def extra_missing(bits, k, gen):
     """bits [n, wps] int64 (het plane | hom plane): OR a mask of bit density 2^-k into
     both planes.  k = 0: nothing."""
@@ -115,6 +126,26 @@ def main():
                 f"records {len(r7)} equal {same} candidates {filt[0]:.1f} dense_quadrants {filt[1]:.1f}")
             if not same:
                 raise SystemExit("variants disagree")
+        del bits
+    # The heterogeneous cohort: 2 % of the samples at ~20 % missing calls (density 2^-2 on
+    # top of the 1 %), the others as they are.
+    hetero = os.environ.get("MISSING_HETERO", "0.02,2")
+    if hetero:
+        frac, k = hetero.split(",")
+        bits, count = heterogeneous_missing(base, float(frac), int(k), gen)
+        for thr in thrs:
+            for sort in (1, 0):
+                ctx.set_option("filter_sort", sort)
+                ms7, r7, filt = run(ctx, 7, sm, wps, bits, thr)
+                ms6, r6, _ = run(ctx, 6, sm, wps, bits, thr)
+                same = r7.tobytes() == r6.tobytes()
+                say(f"heterogeneous: {count} of {n} samples with extra missing calls of density 2^-{k}, "
+                    f"sorted layout {sort}, thr {thr} variant 7 kernel_ms {ms7:.3f} variant 6 kernel_ms "
+                    f"{ms6:.3f} records {len(r7)} equal {same} candidates {filt[0]:.1f} "
+                    f"dense_quadrants {filt[1]:.1f}")
+                if not same:
+                    raise SystemExit("variants disagree")
+        ctx.set_option("filter_sort", 1)
         del bits
     out.close()
 
