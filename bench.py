@@ -160,6 +160,9 @@ def parse_args():
                          "beside it as value_layout_reused")
     ap.add_argument("--convert-every-step", action="store_true",
                     help="(the default since round 4; accepted for old command lines)")
+    ap.add_argument("--no-worst-case", action="store_true",
+                    help="skip roofline.filter_worst_case (the headline cohort with 13 % missing "
+                         "calls, default variant against variant 6)")
     ap.add_argument("--no-h2d-pass", action="store_true",
                     help="skip timing the host-to-device copy of the bitset "
                          "(value_including_h2d)")
@@ -484,6 +487,64 @@ def single_gpu_workload(args, ctx, n, m, thr, steps, warmup, local_rank, clock_p
                                  "check point inside the k loop (no pair of theirs could still "
                                  "become a candidate: king_filter.hip), and the records of a "
                                  "pass"}))
+
+
+def filter_worst_case(args, ctx, bits, n, m, thr, local_rank):
+    """The headline cohort with 12.5 % extra missing calls (a random mask OR-ed into both
+    planes: missing = 11, cuking.cu:507-523) -- beyond the reach of the filter's bound, so
+    the default variant hands every tile to the four-product kernel: one warm-up and two
+    timed passes of the default variant and of variant 6 on the SAME bitset, records
+    compared.  What the default costs when it cannot help."""
+    import torch
+    import cuking_amd
+    dev = f"cuda:{local_rank}"
+    wps = cuking_amd.words_per_sample(m)
+    half = wps // 2
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    dense = bits.clone()
+    mask = None
+    for _ in range(3):                       # density 2^-3
+        r = torch.randint(-(1 << 63), (1 << 63) - 1, (n, half), dtype=torch.int64, device=dev,
+                          generator=gen)
+        mask = r if mask is None else mask & r
+    dense[:, :half] |= mask
+    dense[:, half:2 * half] |= mask
+    del mask, r
+    sm = cuking_amd.Submatrix(n)
+    results = torch.zeros((args.max_results, 6), dtype=torch.int32, device=dev)
+    index_flag = torch.zeros(2, dtype=torch.int32, device=dev)
+    default_variant = ctx.get_option("variant")
+    out = {}
+    recs = {}
+    for name, variant in (("default", default_variant), ("variant_6", 6)):
+        ctx.set_option("variant", variant)
+        ctx.invalidate()
+        times = []
+        for rep in range(3):
+            index_flag.zero_()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.compute_king(sm, wps, dense, thr, args.max_results, results, index_flag[0:1],
+                             index_flag[1:2])
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) * 1e3)
+        count, ovf = index_flag.tolist()
+        if ovf:
+            raise SystemExit("result overflow in the worst-case pass")
+        recs[name] = records_of(results, count)
+        out[name + "_ms_per_step"] = min(times[1:])
+    ctx.set_option("variant", default_variant)
+    ctx.invalidate()
+    if recs["default"].tobytes() != recs["variant_6"].tobytes() and not args.no_check:
+        raise SystemExit("PARITY FAILURE: worst-case pass, default variant != variant 6")
+    out["ratio"] = out["default_ms_per_step"] / out["variant_6_ms_per_step"]
+    out["records"] = int(len(recs["default"]))
+    out["what"] = ("the headline cohort with 12.5 % extra missing calls (13.4 % in all): the "
+                   "filter's bound cannot thin it out and the default hands every tile to the "
+                   "four-product kernel; wall ms of one pass (conversion inside), best of two, "
+                   "the default variant and variant 6 on the same bitset, records identical")
+    return out
 
 
 def dist_workload(args, env, ctx, key, n, m, thr, steps, warmup, headline):
@@ -1086,6 +1147,9 @@ def main():
             workload_key=f"{n}x{m}", clock_mhz=r["clock_mhz"])
         if r["filter"] is not None:
             roofline["filter"] = r["filter"]
+            if not custom and config == "c2" and not args.no_worst_case:
+                roofline["filter_worst_case"] = filter_worst_case(args, ctx, r["bits"], n, m, thr,
+                                                                  local_rank)
         out = {
             "metric": "sample-pairs/s (all-pairs KING)",
             "value": r["pairs"] * args.steps / r["elapsed"],

@@ -128,7 +128,13 @@ struct cuking_ctx {
   // The kernel layout's samples sorted by their share of missing calls (king_sort.hip);
   // the four-product kernel's codes converted only when the filter needs them
   // (0: with every conversion).
-  bool filter_sort = true, filter_lazy_codes = true;
+  // filter_sort: 0 never; 1 (default) whole-block conversions -- cuking_compute_king and
+  // cuking_compute_king_tiles, whose tiles are opaque units of work; 2 also the ranges of
+  // cuking_prepare_samples (for hosts whose rectangles cover every prepared range in full
+  // or in a union, like the staged multi-GPU schedules: inside a sorted range the samples
+  // behind a sub-rectangle are not the ones its bounds name).
+  int filter_sort = 1;
+  bool filter_lazy_codes = true;
   void *sort_temp = nullptr;
   size_t sort_temp_bytes = 0;
 
@@ -594,7 +600,7 @@ cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
   const uint32_t nb = tiles.num_bands();
   cuking_status st = ensure_workspace(ctx, need, (size_t)nb + 1);
   if (st != CUKING_OK) return st;
-  if (v.layout == kLayoutNibbleStats && ctx->filter_sort) {
+  if (v.layout == kLayoutNibbleStats && ctx->filter_sort != 0) {
     st = ensure_sort_temp(ctx, geo.s_stride);
     if (st != CUKING_OK) return st;
   }
@@ -666,7 +672,8 @@ cuking_status prepare(cuking_ctx *ctx, const cuking_submatrix &sm,
     //  this conversion or convert_codes_now() below says so)
     HIP_TRY(hipMemsetAsync(plane_flags(ctx->planes, geo), 0, sizeof(uint32_t), stream));
     HIP_TRY(launch_sample_stats(d_bit_sets, words_per_sample, geo, ctx->planes, sb, se, stream));
-    HIP_TRY(launch_sample_order(geo, words_per_sample, ctx->planes, sb, se, ctx->filter_sort,
+    HIP_TRY(launch_sample_order(geo, words_per_sample, ctx->planes, sb, se,
+                                ctx->filter_sort == 2 || (ctx->filter_sort == 1 && whole),
                                 ctx->sort_temp, ctx->sort_temp_bytes, stream));
     HIP_TRY(launch_prepare_nibbles(codes, true, d_bit_sets, words_per_sample, geo, ctx->planes,
                                    plane_perm(ctx->planes, geo), s_tile_begin, t_end, nullptr,
@@ -919,11 +926,18 @@ cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
     ctx->prepared.valid = false;  // (prefix counts of the workspace belong to the old value)
     return CUKING_OK;
   }
-  if (strcmp(key, "filter_sort") == 0 || strcmp(key, "filter_lazy_codes") == 0) {
-    if (value < 0 || value > 1)
-      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "%s outside [0, 1]", key);
-    (strcmp(key, "filter_sort") == 0 ? ctx->filter_sort : ctx->filter_lazy_codes) = value != 0;
+  if (strcmp(key, "filter_sort") == 0) {
+    if (value < 0 || value > 2)
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "filter_sort outside [0, 2]");
+    ctx->filter_sort = (int)value;
     ctx->prepared.valid = false;  // (the workspace was laid out under the old setting)
+    return CUKING_OK;
+  }
+  if (strcmp(key, "filter_lazy_codes") == 0) {
+    if (value < 0 || value > 1)
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "filter_lazy_codes outside [0, 1]");
+    ctx->filter_lazy_codes = value != 0;
+    ctx->prepared.valid = false;
     return CUKING_OK;
   }
   if (strcmp(key, "filter_check0") == 0) {  // forecast check: 0 off, 1 short launches, 2 always
@@ -1172,7 +1186,7 @@ cuking_status cuking_ctx_get_option(const cuking_ctx *ctx, const char *key,
   else if (strcmp(key, "filter_quadrant_cap") == 0) *value = ctx->filter_quadrant_cap;
   else if (strcmp(key, "filter_cand_cap") == 0) *value = ctx->filter_cand_cap;
   else if (strcmp(key, "filter_split_min_steps") == 0) *value = ctx->filter_split_min_steps;
-  else if (strcmp(key, "filter_sort") == 0) *value = ctx->filter_sort ? 1 : 0;
+  else if (strcmp(key, "filter_sort") == 0) *value = ctx->filter_sort;
   else if (strcmp(key, "filter_lazy_codes") == 0) *value = ctx->filter_lazy_codes ? 1 : 0;
   else if (strcmp(key, "filter_check0") == 0) *value = ctx->filter_check0;
   else if (strcmp(key, "filter_check1") == 0) *value = ctx->filter_check1;
@@ -1439,7 +1453,7 @@ cuking_status cuking_ctx_reserve(cuking_ctx *ctx, const cuking_submatrix *sm,
   const TileSpace tiles = make_tiles(geo, v, ctx->band_rows);
   st = ensure_workspace(ctx, plane_bytes(geo, v.layout), (size_t)tiles.num_bands() + 1);
   if (st != CUKING_OK) return st;
-  if (v.layout == kLayoutNibbleStats && ctx->filter_sort) {
+  if (v.layout == kLayoutNibbleStats && ctx->filter_sort != 0) {
     st = ensure_sort_temp(ctx, geo.s_stride);
     if (st != CUKING_OK) return st;
   }

@@ -14,7 +14,9 @@
 // one broadcast chunk of the staged multi-GPU pass -- any tile-aligned range is a valid
 // unit, since pairs are enumerated in plane order):
 //   1. sample_stats_kernel (king_filter.hip) has left the statistics in STORED order;
-//   2. keys: the missing share in 1/512ths, capped at 255 (8 bits: one radix pass);
+//   2. keys: the missing share in 1/64ths (8 bits: one radix pass) -- coarse on purpose: the
+//      samples of an ordinary cohort (1 % missing calls, give or take) all get key 0 and
+//      the layout IS the stored order;
 //   3. a STABLE sort of (key, sample) pairs -- deterministic, and samples of equal share
 //      (an ordinary cohort: all of them) keep their stored order;
 //   4. perm and the statistics written in plane order; padding samples behind the real
@@ -39,7 +41,7 @@ __global__ void sort_keys_kernel(const float2 *__restrict__ tmp_stats, uint32_t 
   if (p >= n) return;
   const float2 st = tmp_stats[begin + p];
   const float missing = 0.5f * (stored_sites - st.y - st.x);
-  uint32_t key = (uint32_t)(missing * 512.f / stored_sites);
+  uint32_t key = (uint32_t)(missing * 64.f / stored_sites);
   keys[p] = key > 255u ? 255u : key;
   vals[p] = begin + p;
 }

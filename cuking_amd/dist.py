@@ -464,10 +464,18 @@ class GpuStagedOps:
         # broadcast is in flight (cuking_ctx_reserve).
         if not getattr(self, "_reserved", False):
             import torch
+            # (this schedule's rectangles cover every prepared chunk in a union over the
+            #  ranks: the chunks may be laid out sorted by missing share -- library option
+            #  "filter_sort" 2; a host with rectangles of its own keeps the default)
+            self._sort_before = self.ctx.get_option("filter_sort")
+            if self._sort_before == 1:
+                self.ctx.set_option("filter_sort", 2)
             self.ctx.reserve(self.sm, self.wps, [torch.cuda.current_stream()] + self.streams)
             self._reserved = True
             self._at_reserve = (self.ctx.get_option("workspace_allocations"),
                                 self.ctx.get_option("host_syncs"))
+        elif getattr(self, "_sort_before", None) == 1 and self.ctx.get_option("filter_sort") == 1:
+            self.ctx.set_option("filter_sort", 2)
         self.index_flag.zero_()
         self.launches = 0
 
@@ -501,5 +509,9 @@ class GpuStagedOps:
         cur = torch.cuda.current_stream()
         for s in self.streams:
             cur.wait_stream(s)
-        count, overflow = (int(x) & 0xFFFFFFFF for x in self.index_flag.tolist())
+        count, overflow = (int(x) & 0xFFFFFFFF for x in self.index_flag.tolist())   # (waits)
+        if getattr(self, "_sort_before", None) == 1 and self.ctx.get_option("filter_sort") == 2:
+            # (the context goes back to its caller's setting; a later begin() sets it again)
+            self.ctx.set_option("filter_sort", 1)
+            self._reserved_sort_reset = True
         return self.results, min(count, self.max_results), int(overflow)

@@ -349,20 +349,51 @@ void PrintSchedule(const Flags &flags, const cuking_submatrix &sm) {
   std::cout << "]}" << std::endl;
 }
 
-Status Run(const Flags &flags) {
+// One run of the binary, phase by phase (cuking.cu:435-882 is one function; here the
+// phases are functions over this state).
+struct Job {
+  explicit Job(const Flags &f) : flags(f) {}
+  const Flags &flags;
+  bool synthetic = false, multi_gpu = false, dump_only = false;
+  std::string input_dir, output_dir;
+  cuking_host::Metadata metadata;
+  uint32_t num_samples = 0, words_per_sample = 0;
+  cuking_submatrix sm = {0, 0, 0, 0};  // cuking.cu:505
+  size_t bit_set_words = 0, bit_set_bytes = 0;
+  // Input: the tables, the decode tasks ({file, row group or -1 = the whole file}) and
+  // where the triples are packed.
+  std::vector<std::pair<std::string, size_t>> input_files;
+  std::vector<std::pair<size_t, int>> tasks;
+  std::string pack_mode;
+  bool pack_on_device = false;  // the bitset is built in device memory (device pack, synthetic)
+  bool device_pack = false;     // ... from triples, by the GPU
+  DeviceBuffers buf;
+  std::vector<uint64_t> dump_bits;  // --dump_bitset: plain host memory, no GPU
+  uint64_t *host_bits = nullptr;
+  // Measurements for the summary line.
+  std::atomic<size_t> num_triples{0};
+  std::atomic<uint64_t> decode_us{0}, pack_us{0};  // summed over reader threads
+  PackerStats packer_stats;
+  double read_pack_seconds = 0, kernel_seconds = 0;
+  std::ostringstream multi_summary;
+  std::vector<cuking_result> results;
+  StopWatch sw;
+};
+
+// Metadata, the shard's Submatrix and the sizes that follow from them (cuking.cu:475-515).
+Status DescribeInput(Job *job) {
+  const Flags &flags = job->flags;
   {
     const std::string err = cuking_host::ValidateFlags(flags);
     if (!err.empty()) return InvalidArgument(err);
   }
-  const bool synthetic = !flags.synthetic.empty();
-  std::string input_dir, output_dir;
-  if (!synthetic) RETURN_IF_ERROR(ResolveUri(flags.input_uri, &input_dir));
-  RETURN_IF_ERROR(ResolveUri(flags.output_uri, &output_dir));
+  job->synthetic = !flags.synthetic.empty();
+  if (!job->synthetic) RETURN_IF_ERROR(ResolveUri(flags.input_uri, &job->input_dir));
+  RETURN_IF_ERROR(ResolveUri(flags.output_uri, &job->output_dir));
 
-  StopWatch sw;
   std::cout << "Reading metadata..." << std::flush;
-  cuking_host::Metadata metadata;
-  if (synthetic) {
+  cuking_host::Metadata &metadata = job->metadata;
+  if (job->synthetic) {
     metadata.num_sites = flags.synth_sites;
     metadata.samples.reserve(flags.synth_samples);
     char name[16];
@@ -372,149 +403,157 @@ Status Run(const Flags &flags) {
     }
   } else {
     const std::string err =
-        cuking_host::ReadMetadataFile(input_dir + "/metadata.json", &metadata);
+        cuking_host::ReadMetadataFile(job->input_dir + "/metadata.json", &metadata);
     if (!err.empty()) return FailedPrecondition(err);
   }
   if (metadata.samples.size() > 0xFFFFFFFFull)
     return FailedPrecondition("too many samples");
-  const uint32_t num_samples = (uint32_t)metadata.samples.size();
-  const uint32_t words_per_sample = cuking_words_per_sample(metadata.num_sites);
-  Done(&sw);
+  job->num_samples = (uint32_t)metadata.samples.size();
+  job->words_per_sample = cuking_words_per_sample(metadata.num_sites);
+  Done(&job->sw);
 
-  cuking_submatrix sm;  // cuking.cu:505
-  RETURN_IF_ERROR(FromAbi(cuking_submatrix_init(&sm, num_samples, flags.split_factor,
+  RETURN_IF_ERROR(FromAbi(cuking_submatrix_init(&job->sm, job->num_samples, flags.split_factor,
                                                 flags.shard_index)));
+  job->multi_gpu = flags.num_gpus > 0;
+  job->bit_set_words = (size_t)job->words_per_sample * cuking_submatrix_num_samples(&job->sm);
+  job->bit_set_bytes = job->bit_set_words * sizeof(uint64_t);
+  job->dump_only = !flags.dump_bitset.empty();
+  return Status::Ok();
+}
 
-  if (flags.print_schedule) {  // host arithmetic only: no GPU, no input tables
-    PrintSchedule(flags, sm);
-    return Status::Ok();
-  }
-  const bool multi_gpu = flags.num_gpus > 0;
-
-  const size_t bit_set_words =
-      (size_t)words_per_sample * cuking_submatrix_num_samples(&sm);
-  const size_t bit_set_bytes = bit_set_words * sizeof(uint64_t);
-  const bool dump_only = !flags.dump_bitset.empty();
-  if (dump_only && synthetic)
+// The input tables (cuking.cu:529-545), where their triples are packed, and the decode
+// tasks: one per (file, row group) when the files are fewer than the reader threads -- the
+// reference hands out whole files (cuking.cu:550-553), which caps the decode at one thread
+// per file; a table written with several row groups decodes on several.
+Status PlanInput(Job *job) {
+  const Flags &flags = job->flags;
+  if (job->dump_only && job->synthetic)
     return InvalidArgument("--dump_bitset needs input tables, not --synthetic");
   // (a synthetic cohort is generated on the GPU: from here on it is a bitset
   //  that already sits in device memory, like a device-packed one)
-  // --pack=auto is resolved once the input is listed (below): the device pack
-  // pays ~0.1 s of set-up (page-locked rings, streams) and wins while the GPU's
-  // atomics keep up with the readers.
-  std::string pack_mode = flags.pack;
-  std::vector<std::pair<std::string, size_t>> input_files;
-  if (!synthetic) {  // (listed before anything is allocated: the pack mode depends on it)
+  job->pack_mode = flags.pack;
+  if (!job->synthetic) {  // (listed before anything is allocated: the pack mode depends on it)
     std::cout << "Listing input files..." << std::flush;
-    RETURN_IF_ERROR(ListParquetFiles(input_dir, &input_files));
-    Done(&sw);
-    if (input_files.empty()) return FailedPrecondition("No input files found");  // :542-544
-    std::cout << "Found " << input_files.size() << " input files." << std::endl;
+    RETURN_IF_ERROR(ListParquetFiles(job->input_dir, &job->input_files));
+    Done(&job->sw);
+    if (job->input_files.empty()) return FailedPrecondition("No input files found");  // :542-544
+    std::cout << "Found " << job->input_files.size() << " input files." << std::endl;
   }
-  if (pack_mode == "auto") {
-    // Measured on MI355X boxes (profiles/r03_pack_pipeline.txt): with up to ~32
-    // reader threads per GPU and an input of a gigabyte or more the pipelined
-    // device pack is ahead (1e9 triples: +37 %); below that its set-up is not
-    // amortised (1e8 triples: 0.27 s against 0.20 s), and beyond ~32 threads the
-    // host's cores outrun one GPU's atomic units.
+  if (job->pack_mode == "auto") {
+    // The device pack pays ~0.1 s of set-up (page-locked rings, streams) and wins while
+    // the GPU's atomics keep up with the readers.  Measured on MI355X boxes
+    // (profiles/r03_pack_pipeline.txt): with up to ~32 reader threads per GPU and an input
+    // of a gigabyte or more the pipelined device pack is ahead (1e9 triples: +37 %); below
+    // that its set-up is not amortised (1e8 triples: 0.27 s against 0.20 s), and beyond ~32
+    // threads the host's cores outrun one GPU's atomic units.
     // (the reader threads that can run at once: the flag's default is the reference's 36,
     //  cuking.cu:36, whatever the box -- a GPU's share of a node is 16 hardware threads)
     size_t input_bytes = 0;
-    for (const auto &f : input_files) input_bytes += f.second;
+    for (const auto &f : job->input_files) input_bytes += f.second;
     const size_t hw = std::max(1u, std::thread::hardware_concurrency());
     const size_t running = std::min(flags.num_reader_threads, hw);
-    pack_mode = (running <= 32 && input_bytes >= (size_t(1) << 30)) ? "device" : "host";
+    job->pack_mode = (running <= 32 && input_bytes >= (size_t(1) << 30)) ? "device" : "host";
   }
-  const bool pack_on_device = (pack_mode == "device" || synthetic) && !dump_only;
+  job->pack_on_device = (job->pack_mode == "device" || job->synthetic) && !job->dump_only;
+  job->device_pack = job->pack_on_device && !job->synthetic;
+  if (!job->synthetic) {
+    const auto &files = job->input_files;
+    if (files.size() >= flags.num_reader_threads) {
+      for (size_t f = 0; f < files.size(); ++f) job->tasks.emplace_back(f, -1);
+    } else {
+      std::vector<int> groups(files.size(), 1);
+      const std::string err = cuking_host::ParallelFor(
+          flags.num_reader_threads, 0, files.size(), [&](size_t f) -> std::string {
+            return cuking_host::CountRowGroups(files[f].first, &groups[f]);
+          });
+      if (!err.empty()) return FailedPrecondition(err);
+      for (size_t f = 0; f < files.size(); ++f) {
+        if (groups[f] <= 1) job->tasks.emplace_back(f, -1);
+        else for (int g = 0; g < groups[f]; ++g) job->tasks.emplace_back(f, g);
+      }
+    }
+  }
+  return Status::Ok();
+}
 
-  DeviceBuffers buf;
-  std::vector<uint64_t> dump_bits;  // --dump_bitset: plain host memory, no GPU
-  std::cout << "Allocating " << CeilMiB(bit_set_bytes)
+// The bitset, everything missing (cuking.cu:516-523): device memory for the device pack
+// and the synthetic cohort, a page-locked staging buffer for the host pack.
+Status AllocateBitSet(Job *job) {
+  const Flags &flags = job->flags;
+  DeviceBuffers &buf = job->buf;
+  std::cout << "Allocating " << CeilMiB(job->bit_set_bytes)
             << " MiB of memory for bit set..." << std::flush;
-  if (dump_only) {
-    dump_bits.assign(bit_set_words, ~0ull);
+  if (job->dump_only) {
+    job->dump_bits.assign(job->bit_set_words, ~0ull);
   } else {
     RETURN_IF_ERROR(FromAbi(cuking_ctx_create(flags.device, &buf.ctx)));
     RETURN_IF_ERROR(FromAbi(cuking_ctx_set_kernel(
         buf.ctx,
         flags.kernel == "stream" ? CUKING_KERNEL_STREAM : CUKING_KERNEL_TILED)));
     // (with --num_gpus and host pack every rank allocates its own copy later)
-    if (!multi_gpu || pack_on_device)
-      RETURN_IF_ERROR(FromAbi(cuking_device_alloc(buf.ctx, bit_set_bytes, &buf.d_bits)));
-    if (synthetic) {
+    if (!job->multi_gpu || job->pack_on_device)
+      RETURN_IF_ERROR(FromAbi(cuking_device_alloc(buf.ctx, job->bit_set_bytes, &buf.d_bits)));
+    if (job->synthetic) {
       // every word is written by the generator
-    } else if (pack_on_device) {
+    } else if (job->pack_on_device) {
       RETURN_IF_ERROR(FromAbi(
-          cuking_memset_async(buf.ctx, buf.d_bits, 0xFF, bit_set_bytes, nullptr)));
+          cuking_memset_async(buf.ctx, buf.d_bits, 0xFF, job->bit_set_bytes, nullptr)));
     } else {
-      // Page-locked staging buffer; all ones = everything missing
-      // (cuking.cu:520-523).
-      RETURN_IF_ERROR(FromAbi(cuking_host_alloc(buf.ctx, bit_set_bytes, &buf.host_bits)));
-      if (bit_set_bytes) memset(buf.host_bits, 0xFF, bit_set_bytes);
+      RETURN_IF_ERROR(FromAbi(cuking_host_alloc(buf.ctx, job->bit_set_bytes, &buf.host_bits)));
+      if (job->bit_set_bytes) memset(buf.host_bits, 0xFF, job->bit_set_bytes);
     }
   }
-  uint64_t *host_bits =
-      dump_only ? dump_bits.data() : static_cast<uint64_t *>(buf.host_bits);
-  Done(&sw);
+  job->host_bits =
+      job->dump_only ? job->dump_bits.data() : static_cast<uint64_t *>(buf.host_bits);
+  Done(&job->sw);
+  return Status::Ok();
+}
 
-  const bool device_pack = pack_on_device && !synthetic;  // triples packed by the GPU
-  // Decode tasks: one per (file, row group) when the files are fewer than the
-  // reader threads -- the reference hands out whole files (cuking.cu:550-553),
-  // which caps the decode at one thread per file; a table written with several
-  // row groups decodes on several.  {file, row group or -1 = the whole file}.
-  std::vector<std::pair<size_t, int>> tasks;
-  if (!synthetic) {
-    if (input_files.size() >= flags.num_reader_threads) {
-      for (size_t f = 0; f < input_files.size(); ++f) tasks.emplace_back(f, -1);
-    } else {
-      std::vector<int> groups(input_files.size(), 1);
-      const std::string err = cuking_host::ParallelFor(
-          flags.num_reader_threads, 0, input_files.size(), [&](size_t f) -> std::string {
-            return cuking_host::CountRowGroups(input_files[f].first, &groups[f]);
-          });
-      if (!err.empty()) return FailedPrecondition(err);
-      for (size_t f = 0; f < input_files.size(); ++f) {
-        if (groups[f] <= 1) tasks.emplace_back(f, -1);
-        else for (int g = 0; g < groups[f]; ++g) tasks.emplace_back(f, g);
-      }
-    }
-  }
+// --synthetic: founders + planted relatives (synth_plan.h), genotypes from the device
+// generator, straight into the reference layout: rows of the shard first, then its
+// columns (cuking.cu:171-175).
+Status SynthesiseCohort(Job *job) {
+  const Flags &flags = job->flags;
+  DeviceBuffers &buf = job->buf;
+  const cuking_submatrix &sm = job->sm;
+  const uint32_t num_samples = job->num_samples, words_per_sample = job->words_per_sample;
+  const cuking_host::CohortPlan plan = cuking_host::PlanCohort(num_samples, flags.synth_seed);
+  void *d_plan = nullptr;
+  const size_t plan_bytes = (size_t)num_samples * sizeof(uint32_t);
+  RETURN_IF_ERROR(FromAbi(cuking_device_alloc(buf.ctx, 3 * plan_bytes, &d_plan)));
+  uint32_t *d_kind = static_cast<uint32_t *>(d_plan);
+  uint32_t *d_pa = d_kind + num_samples, *d_pb = d_pa + num_samples;
+  cuking_status st = cuking_copy_to_device(buf.ctx, d_kind, plan.kind.data(), plan_bytes, nullptr);
+  if (st == CUKING_OK) st = cuking_copy_to_device(buf.ctx, d_pa, plan.pa.data(), plan_bytes, nullptr);
+  if (st == CUKING_OK) st = cuking_copy_to_device(buf.ctx, d_pb, plan.pb.data(), plan_bytes, nullptr);
+  uint64_t *d_bits = static_cast<uint64_t *>(buf.d_bits);
+  if (st == CUKING_OK)
+    st = cuking_synth_bitset(buf.ctx, flags.synth_seed, d_kind, d_pa, d_pb, sm.i_begin, sm.i_end,
+                             job->metadata.num_sites, words_per_sample, d_bits, nullptr);
+  if (st == CUKING_OK && sm.i_begin != sm.j_begin)
+    st = cuking_synth_bitset(buf.ctx, flags.synth_seed, d_kind, d_pa, d_pb, sm.j_begin, sm.j_end,
+                             job->metadata.num_sites, words_per_sample,
+                             d_bits + (size_t)(sm.i_end - sm.i_begin) * words_per_sample, nullptr);
+  if (st == CUKING_OK) st = cuking_stream_synchronize(buf.ctx, nullptr);
+  cuking_device_free(buf.ctx, d_plan);
+  return FromAbi(st);
+}
 
-  std::cout << (synthetic ? "Synthesising genotypes on the GPU..." : "Processing Parquet tables...")
-            << std::flush;
-  if (synthetic) {
-    // Founders + planted relatives (synth_plan.h), genotypes from the device
-    // generator, straight into the reference layout: rows of the shard first,
-    // then its columns (cuking.cu:171-175).
-    const cuking_host::CohortPlan plan =
-        cuking_host::PlanCohort(num_samples, flags.synth_seed);
-    void *d_plan = nullptr;
-    const size_t plan_bytes = (size_t)num_samples * sizeof(uint32_t);
-    RETURN_IF_ERROR(FromAbi(cuking_device_alloc(buf.ctx, 3 * plan_bytes, &d_plan)));
-    uint32_t *d_kind = static_cast<uint32_t *>(d_plan);
-    uint32_t *d_pa = d_kind + num_samples, *d_pb = d_pa + num_samples;
-    cuking_status st = cuking_copy_to_device(buf.ctx, d_kind, plan.kind.data(), plan_bytes, nullptr);
-    if (st == CUKING_OK) st = cuking_copy_to_device(buf.ctx, d_pa, plan.pa.data(), plan_bytes, nullptr);
-    if (st == CUKING_OK) st = cuking_copy_to_device(buf.ctx, d_pb, plan.pb.data(), plan_bytes, nullptr);
-    uint64_t *d_bits = static_cast<uint64_t *>(buf.d_bits);
-    if (st == CUKING_OK)
-      st = cuking_synth_bitset(buf.ctx, flags.synth_seed, d_kind, d_pa, d_pb, sm.i_begin, sm.i_end,
-                               metadata.num_sites, words_per_sample, d_bits, nullptr);
-    if (st == CUKING_OK && sm.i_begin != sm.j_begin)
-      st = cuking_synth_bitset(buf.ctx, flags.synth_seed, d_kind, d_pa, d_pb, sm.j_begin, sm.j_end,
-                               metadata.num_sites, words_per_sample,
-                               d_bits + (size_t)(sm.i_end - sm.i_begin) * words_per_sample, nullptr);
-    if (st == CUKING_OK) st = cuking_stream_synchronize(buf.ctx, nullptr);
-    cuking_device_free(buf.ctx, d_plan);
-    RETURN_IF_ERROR(FromAbi(st));
-  }
-  std::atomic<size_t> num_processed(0), num_triples(0);
-  std::atomic<uint64_t> decode_us(0), pack_us(0);  // summed over reader threads
-  auto now_us = []() {
-    return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(
-               std::chrono::steady_clock::now().time_since_epoch()).count();
-  };
-  PackerStats packer_stats;
+// Decode + pack on the reader threads (cuking.cu:547-711): every task's triples into the
+// bitset, by the host's relaxed atomics or through a reader thread's device packer; then
+// the bitset is where the kernel (or the broadcast) expects it.
+Status DecodeAndPack(Job *job) {
+  const Flags &flags = job->flags;
+  DeviceBuffers &buf = job->buf;
+  const cuking_submatrix &sm = job->sm;
+  const uint32_t words_per_sample = job->words_per_sample;
+  const bool device_pack = job->device_pack;
+  uint64_t *const host_bits = job->host_bits;
+  const auto &tasks = job->tasks;
+  const auto &input_files = job->input_files;
+  std::atomic<size_t> num_processed(0);
+  auto now_us = []() { return NowMicros(); };
+  PackerStats &packer_stats = job->packer_stats;
   std::vector<std::unique_ptr<DevicePacker>> packers;
   uint32_t *d_pack_status = nullptr;
   std::atomic<size_t> next_packer(0);
@@ -566,6 +605,9 @@ Status Run(const Flags &flags) {
       if (t.joinable()) t.join();
     }
   } joiner{setup_thread};
+  // --decode=auto: batches of triples packed as they are decoded, for both packs (the
+  // streaming form measured ahead of whole tables on a GPU box: profiles/r04_pack_pipeline.txt).
+  const bool stream_decode = flags.decode != "table";
   const std::string pack_error = cuking_host::ParallelFor(
       flags.num_reader_threads, 0, tasks.size(), [&](size_t task) -> std::string {
         const size_t f = tasks[task].first;
@@ -594,9 +636,9 @@ Status Run(const Flags &flags) {
         };
         const uint64_t t_begin = now_us();
         size_t n = 0;
-        if (flags.decode == "stream" || (flags.decode == "auto" && !device_pack)) {
-          // Batches packed as they are decoded: small enough to stay in the cache for
-          // the host pack, one staging slot's worth for the device pack.
+        if (stream_decode) {
+          // Batches small enough to stay in the cache for the host pack, one staging
+          // slot's worth for the device pack.
           BatchSink sink(pack);
           thread_local cuking_host::TripleScratch scratch;
           const size_t batch = flags.decode_batch != 0 ? flags.decode_batch
@@ -611,20 +653,20 @@ Status Run(const Flags &flags) {
                        : "FAILED_PRECONDITION\n" + err;
           n = sink.triples;
           const uint64_t total = now_us() - t_begin;
-          pack_us += sink.pack_time_us;
-          decode_us += total > sink.pack_time_us ? total - sink.pack_time_us : 0;
+          job->pack_us += sink.pack_time_us;
+          job->decode_us += total > sink.pack_time_us ? total - sink.pack_time_us : 0;
         } else {
           cuking_host::Triples t;
           std::string err = cuking_host::ReadTriples(path, tasks[task].second, &t);
           if (!err.empty()) return "FAILED_PRECONDITION\n" + err;
           n = t.row_idx.size();
           const uint64_t t_decoded = now_us();
-          decode_us += t_decoded - t_begin;
+          job->decode_us += t_decoded - t_begin;
           err = pack(t.row_idx.data(), t.col_idx.data(), t.n_alt_alleles.data(), n);
           if (!err.empty()) return err;
-          pack_us += now_us() - t_decoded;
+          job->pack_us += now_us() - t_decoded;
         }
-        num_triples += n;
+        job->num_triples += n;
         if ((++num_processed & 1023) == 0) std::cout << "." << std::flush;  // :705-708
         return "";
       });
@@ -636,18 +678,7 @@ Status Run(const Flags &flags) {
     return {pack_error.substr(0, nl), pack_error.substr(nl + 1)};
   }
   if (device_pack && !setup_error.empty()) return {"INTERNAL", setup_error};
-  if (dump_only) {
-    Done(&sw);
-    FILE *f = fopen(flags.dump_bitset.c_str(), "wb");
-    if (f == nullptr) return Unknown("Cannot write " + flags.dump_bitset);
-    const size_t wrote = fwrite(dump_bits.data(), sizeof(uint64_t), bit_set_words, f);
-    fclose(f);
-    if (wrote != bit_set_words) return Unknown("Short write to " + flags.dump_bitset);
-    std::cout << "Dumped " << bit_set_words << " words (" << num_triples.load()
-              << " triples, " << tasks.size() << " decode tasks) to " << flags.dump_bitset
-              << std::endl;
-    return Status::Ok();
-  }
+  if (job->dump_only) return Status::Ok();
   if (device_pack) {
     for (auto &p : packers) {
       const std::string msg = p->Finish();
@@ -663,130 +694,150 @@ Status Run(const Flags &flags) {
       return FailedPrecondition("Invalid value for n_alt_alleles encountered");
     if (pack_status & 2u)
       return InvalidArgument("row_idx outside the padded sites encountered");
-  } else if (!multi_gpu && !synthetic) {
+  } else if (!job->multi_gpu && !job->synthetic) {
     RETURN_IF_ERROR(FromAbi(cuking_copy_to_device(buf.ctx, buf.d_bits, buf.host_bits,
-                                                  bit_set_bytes, nullptr)));
+                                                  job->bit_set_bytes, nullptr)));
     RETURN_IF_ERROR(FromAbi(cuking_stream_synchronize(buf.ctx, nullptr)));
     cuking_host_free(buf.ctx, buf.host_bits);
     buf.host_bits = nullptr;
   }
-  // (list -> decode -> pack -> bitset on the GPU; with --num_gpus and host pack
-  //  the upload belongs to the broadcast that follows)
-  const double read_pack_seconds = sw.ElapsedAndReset();
-  std::cout << " (" << std::fixed << std::setprecision(3) << read_pack_seconds << "s)"
+  return Status::Ok();
+}
+
+// --dump_bitset: the packed host bitset as raw little-endian u64, no GPU.
+Status DumpBitSet(Job *job) {
+  const Flags &flags = job->flags;
+  Done(&job->sw);
+  FILE *f = fopen(flags.dump_bitset.c_str(), "wb");
+  if (f == nullptr) return Unknown("Cannot write " + flags.dump_bitset);
+  const size_t wrote = fwrite(job->dump_bits.data(), sizeof(uint64_t), job->bit_set_words, f);
+  fclose(f);
+  if (wrote != job->bit_set_words) return Unknown("Short write to " + flags.dump_bitset);
+  std::cout << "Dumped " << job->bit_set_words << " words (" << job->num_triples.load()
+            << " triples, " << job->tasks.size() << " decode tasks) to " << flags.dump_bitset
+            << std::endl;
+  return Status::Ok();
+}
+
+// The shard over flags.num_gpus GPUs: chunked RCCL broadcast of the packed bitset,
+// pair-space shares per rank, records gathered on rank 0 (multi_gpu.h).
+Status ComputeOnSeveralGpus(Job *job) {
+  const Flags &flags = job->flags;
+  DeviceBuffers &buf = job->buf;
+  std::cout << "Running KING HIP kernel for " << cuking_submatrix_num_rows(&job->sm) << " x "
+            << cuking_submatrix_num_cols(&job->sm) << " matrix on " << flags.num_gpus
+            << " GPU(s)..." << std::flush;
+  cuking_host::MultiGpuInput in;
+  in.num_gpus = (int)flags.num_gpus;
+  in.first_device = flags.device;
+  in.kernel = flags.kernel;
+  in.mode = flags.multi_gpu_mode;
+  in.chunks = flags.bcast_chunks;
+  in.sm = job->sm;
+  in.words_per_sample = job->words_per_sample;
+  in.host_bits = job->pack_on_device ? nullptr : static_cast<const uint64_t *>(buf.host_bits);
+  in.d_bits_rank0 = static_cast<uint64_t *>(buf.d_bits);
+  in.kin_threshold = flags.kin_threshold;
+  in.max_results = flags.max_results;
+  in.collectives = flags.collectives;
+  in.rank_weights = flags.rank_weight_values;
+  in.calibrate = flags.calibrate;
+  in.calibration_tiles = flags.calibration_tiles;
+  in.inject_failure_rank = flags.inject_failure_rank;
+  in.inject_failure_phase = flags.inject_failure_phase;
+  in.phase_timeout_seconds = flags.phase_timeout_seconds;
+  cuking_host::MultiGpuOutput mg;
+  std::string code;
+  const std::string err = cuking_host::RunMultiGpu(in, &mg, &code);
+  if (!err.empty()) return {code, err};
+  // kernel_seconds = exchange + compute + gather; the communicator set-up
+  // (seconds in a cold process) and the per-GPU contexts are reported apart
+  const double wall = job->sw.ElapsedAndReset();
+  job->kernel_seconds = mg.exchange_and_compute_seconds + mg.gather_seconds;
+  std::cout << " (" << std::fixed << std::setprecision(3) << job->kernel_seconds
+            << "s; with RCCL set-up " << wall << "s)" << std::endl;
+  job->results.swap(mg.results);
+  std::ostringstream &out = job->multi_summary;
+  auto list = [&](const char *key, const auto &values, int precision) {
+    out << ", \"" << key << "\": [";
+    for (size_t r = 0; r < values.size(); ++r)
+      out << (r ? ", " : "") << std::setprecision(precision) << values[r];
+    out << "]";
+  };
+  out << ", \"gpus\": " << flags.num_gpus << ", \"multi_gpu_wall_seconds\": "
+      << std::setprecision(3) << wall << ", \"comm_init_seconds\": " << mg.comm_init_seconds
+      << ", \"multi_gpu_mode\": \"" << mg.mode << "\", \"bytes_broadcast\": "
+      << mg.bytes_broadcast << ", \"exchange_and_compute_seconds\": " << std::setprecision(6)
+      << mg.exchange_and_compute_seconds << ", \"gather_seconds\": " << mg.gather_seconds;
+  list("rank_kernel_ms", mg.rank_kernel_ms, 3);
+  list("rank_results", mg.rank_results, 6);
+  out << ", \"collectives\": \"" << mg.collectives << "\"";
+  list("allocations_after_reserve", mg.rank_allocations_after_reserve, 6);
+  list("host_syncs_after_reserve", mg.rank_host_syncs_after_reserve, 6);
+  out << ", \"calibration_tiles\": " << mg.calibration_tiles;
+  list("rank_rates_tiles_per_ms", mg.rank_rates, 4);
+  out << ", \"rank_tile_ranges\": [";
+  for (size_t r = 0; r < mg.rank_tile_ranges.size(); ++r)
+    out << (r ? ", " : "") << "[" << mg.rank_tile_ranges[r].first << ", "
+        << mg.rank_tile_ranges[r].second << "]";
+  out << "]";
+  if (buf.host_bits) {
+    cuking_host_free(buf.ctx, buf.host_bits);
+    buf.host_bits = nullptr;
+  }
+  std::cout << "Processing " << job->results.size() << " results..." << std::flush;
+  return Status::Ok();
+}
+
+// The reference's path (cuking.cu:713-756): one kernel call through the C ABI, the
+// overflow check, the records back on the host.
+Status ComputeOnOneGpu(Job *job) {
+  const Flags &flags = job->flags;
+  DeviceBuffers &buf = job->buf;
+  const uint32_t max_results = flags.max_results;
+  std::cout << "Allocating " << CeilMiB((uint64_t)max_results * sizeof(cuking_result))
+            << " MiB of memory for results..." << std::flush;
+  RETURN_IF_ERROR(FromAbi(cuking_device_alloc(
+      buf.ctx, (size_t)max_results * sizeof(cuking_result), &buf.d_results)));
+  RETURN_IF_ERROR(
+      FromAbi(cuking_device_alloc(buf.ctx, 2 * sizeof(uint32_t), &buf.d_counters)));
+  RETURN_IF_ERROR(FromAbi(
+      cuking_memset_async(buf.ctx, buf.d_counters, 0, 2 * sizeof(uint32_t), nullptr)));
+  Done(&job->sw);
+
+  std::cout << "Running KING HIP kernel for " << cuking_submatrix_num_rows(&job->sm) << " x "
+            << cuking_submatrix_num_cols(&job->sm) << " matrix..." << std::flush;
+  uint32_t *d_counters = static_cast<uint32_t *>(buf.d_counters);
+  RETURN_IF_ERROR(FromAbi(cuking_compute_king(
+      buf.ctx, &job->sm, job->words_per_sample, static_cast<uint64_t *>(buf.d_bits),
+      flags.kin_threshold, max_results, static_cast<cuking_result *>(buf.d_results),
+      d_counters, d_counters + 1, nullptr)));
+  uint32_t counters[2] = {0, 0};
+  RETURN_IF_ERROR(FromAbi(cuking_copy_to_host(buf.ctx, counters, d_counters,
+                                              sizeof(counters), nullptr)));
+  RETURN_IF_ERROR(FromAbi(cuking_stream_synchronize(buf.ctx, nullptr)));  // errors surface here
+  job->kernel_seconds = job->sw.ElapsedAndReset();
+  std::cout << " (" << std::fixed << std::setprecision(3) << job->kernel_seconds << "s)"
             << std::endl;
 
-  const uint32_t num_rows = cuking_submatrix_num_rows(&sm);
-  const uint32_t num_cols = cuking_submatrix_num_cols(&sm);
-  std::vector<cuking_result> results;
-  double kernel_seconds = 0;
-  std::ostringstream multi_summary;
-  if (multi_gpu) {
-    // The shard over flags.num_gpus GPUs: chunked RCCL broadcast of the packed
-    // bitset, pair-space shares per rank, records gathered on rank 0.
-    std::cout << "Running KING HIP kernel for " << num_rows << " x " << num_cols
-              << " matrix on " << flags.num_gpus << " GPU(s)..." << std::flush;
-    cuking_host::MultiGpuInput in;
-    in.num_gpus = (int)flags.num_gpus;
-    in.first_device = flags.device;
-    in.kernel = flags.kernel;
-    in.mode = flags.multi_gpu_mode;
-    in.chunks = flags.bcast_chunks;
-    in.sm = sm;
-    in.words_per_sample = words_per_sample;
-    in.host_bits = pack_on_device ? nullptr : static_cast<const uint64_t *>(buf.host_bits);
-    in.d_bits_rank0 = static_cast<uint64_t *>(buf.d_bits);
-    in.kin_threshold = flags.kin_threshold;
-    in.max_results = flags.max_results;
-    in.collectives = flags.collectives;
-    in.rank_weights = flags.rank_weight_values;
-    in.calibrate = flags.calibrate;
-    in.calibration_tiles = flags.calibration_tiles;
-    in.inject_failure_rank = flags.inject_failure_rank;
-    in.inject_failure_phase = flags.inject_failure_phase;
-    in.phase_timeout_seconds = flags.phase_timeout_seconds;
-    cuking_host::MultiGpuOutput mg;
-    std::string code;
-    const std::string err = cuking_host::RunMultiGpu(in, &mg, &code);
-    if (!err.empty()) return {code, err};
-    // kernel_seconds = exchange + compute + gather; the communicator set-up
-    // (seconds in a cold process) and the per-GPU contexts are reported apart
-    const double wall = sw.ElapsedAndReset();
-    kernel_seconds = mg.exchange_and_compute_seconds + mg.gather_seconds;
-    std::cout << " (" << std::fixed << std::setprecision(3) << kernel_seconds << "s; with RCCL "
-              << "set-up " << wall << "s)" << std::endl;
-    results.swap(mg.results);
-    multi_summary << ", \"gpus\": " << flags.num_gpus << ", \"multi_gpu_wall_seconds\": "
-                  << std::setprecision(3) << wall << ", \"comm_init_seconds\": "
-                  << mg.comm_init_seconds << ", \"multi_gpu_mode\": \"" << mg.mode
-                  << "\", \"bytes_broadcast\": " << mg.bytes_broadcast
-                  << ", \"exchange_and_compute_seconds\": " << std::setprecision(6)
-                  << mg.exchange_and_compute_seconds << ", \"gather_seconds\": "
-                  << mg.gather_seconds << ", \"rank_kernel_ms\": [";
-    for (size_t r = 0; r < mg.rank_kernel_ms.size(); ++r)
-      multi_summary << (r ? ", " : "") << std::setprecision(3) << mg.rank_kernel_ms[r];
-    multi_summary << "], \"rank_results\": [";
-    for (size_t r = 0; r < mg.rank_results.size(); ++r)
-      multi_summary << (r ? ", " : "") << mg.rank_results[r];
-    multi_summary << "], \"collectives\": \"" << mg.collectives
-                  << "\", \"allocations_after_reserve\": [";
-    for (size_t r = 0; r < mg.rank_allocations_after_reserve.size(); ++r)
-      multi_summary << (r ? ", " : "") << mg.rank_allocations_after_reserve[r];
-    multi_summary << "], \"host_syncs_after_reserve\": [";
-    for (size_t r = 0; r < mg.rank_host_syncs_after_reserve.size(); ++r)
-      multi_summary << (r ? ", " : "") << mg.rank_host_syncs_after_reserve[r];
-    multi_summary << "], \"calibration_tiles\": " << mg.calibration_tiles
-                  << ", \"rank_rates_tiles_per_ms\": [";
-    for (size_t r = 0; r < mg.rank_rates.size(); ++r)
-      multi_summary << (r ? ", " : "") << std::setprecision(4) << mg.rank_rates[r];
-    multi_summary << "], \"rank_tile_ranges\": [";
-    for (size_t r = 0; r < mg.rank_tile_ranges.size(); ++r)
-      multi_summary << (r ? ", " : "") << "[" << mg.rank_tile_ranges[r].first << ", "
-                    << mg.rank_tile_ranges[r].second << "]";
-    multi_summary << "]";
-    if (buf.host_bits) {
-      cuking_host_free(buf.ctx, buf.host_bits);
-      buf.host_bits = nullptr;
-    }
-    std::cout << "Processing " << results.size() << " results..." << std::flush;
-  } else {
-    const uint32_t max_results = flags.max_results;
-    std::cout << "Allocating " << CeilMiB((uint64_t)max_results * sizeof(cuking_result))
-              << " MiB of memory for results..." << std::flush;
-    RETURN_IF_ERROR(FromAbi(cuking_device_alloc(
-        buf.ctx, (size_t)max_results * sizeof(cuking_result), &buf.d_results)));
-    RETURN_IF_ERROR(
-        FromAbi(cuking_device_alloc(buf.ctx, 2 * sizeof(uint32_t), &buf.d_counters)));
-    RETURN_IF_ERROR(FromAbi(
-        cuking_memset_async(buf.ctx, buf.d_counters, 0, 2 * sizeof(uint32_t), nullptr)));
-    Done(&sw);
+  if (counters[1] != 0)  // cuking.cu:747-751
+    return ResourceExhausted(
+        "Could not store all results: try increasing the --max_results parameter.");
 
-    std::cout << "Running KING HIP kernel for " << num_rows << " x " << num_cols
-              << " matrix..." << std::flush;
-    uint32_t *d_counters = static_cast<uint32_t *>(buf.d_counters);
-    RETURN_IF_ERROR(FromAbi(cuking_compute_king(
-        buf.ctx, &sm, words_per_sample, static_cast<uint64_t *>(buf.d_bits),
-        flags.kin_threshold, max_results, static_cast<cuking_result *>(buf.d_results),
-        d_counters, d_counters + 1, nullptr)));
-    uint32_t counters[2] = {0, 0};
-    RETURN_IF_ERROR(FromAbi(cuking_copy_to_host(buf.ctx, counters, d_counters,
-                                                sizeof(counters), nullptr)));
-    RETURN_IF_ERROR(FromAbi(cuking_stream_synchronize(buf.ctx, nullptr)));  // errors surface here
-    kernel_seconds = sw.ElapsedAndReset();
-    std::cout << " (" << std::fixed << std::setprecision(3) << kernel_seconds << "s)"
-              << std::endl;
+  std::cout << "Processing " << counters[0] << " results..." << std::flush;
+  job->results.resize(counters[0]);
+  RETURN_IF_ERROR(FromAbi(cuking_copy_to_host(buf.ctx, job->results.data(), buf.d_results,
+                                              job->results.size() * sizeof(cuking_result),
+                                              nullptr)));
+  return FromAbi(cuking_stream_synchronize(buf.ctx, nullptr));
+}
 
-    if (counters[1] != 0)  // cuking.cu:747-751
-      return ResourceExhausted(
-          "Could not store all results: try increasing the --max_results parameter.");
-
-    std::cout << "Processing " << counters[0] << " results..." << std::flush;
-    results.resize(counters[0]);
-    RETURN_IF_ERROR(FromAbi(cuking_copy_to_host(buf.ctx, results.data(), buf.d_results,
-                                                results.size() * sizeof(cuking_result),
-                                                nullptr)));
-    RETURN_IF_ERROR(FromAbi(cuking_stream_synchronize(buf.ctx, nullptr)));
-  }
+// Sort, part-<shard>.snappy.parquet (cuking.cu:757-879), and the machine-readable summary
+// (extends the reference's phase log).
+Status WriteOutput(Job *job) {
+  const Flags &flags = job->flags;
+  DeviceBuffers &buf = job->buf;
+  std::vector<cuking_result> &results = job->results;
   const size_t num_results = results.size();
   // Free device memory before post-processing (cuking.cu:757-758).
   if (buf.d_bits) {
@@ -795,51 +846,81 @@ Status Run(const Flags &flags) {
   }
   cuking_sort_results(results.data(), results.size());  // :761-765
 
-  RETURN_IF_ERROR(MakeDirs(output_dir));
+  RETURN_IF_ERROR(MakeDirs(job->output_dir));
   std::ostringstream name;  // :868-870
-  name << output_dir << "/part-" << std::setw(5) << std::setfill('0') << flags.shard_index
+  name << job->output_dir << "/part-" << std::setw(5) << std::setfill('0') << flags.shard_index
        << ".snappy.parquet";
   uint64_t bytes_written = 0;
   {
     const std::string err = cuking_host::WriteResults(
-        name.str(), results.data(), results.size(), metadata.samples, &bytes_written);
+        name.str(), results.data(), results.size(), job->metadata.samples, &bytes_written);
     if (!err.empty()) return Unknown(err);
   }
-  Done(&sw);
+  Done(&job->sw);
   std::cout << "Wrote " << CeilMiB(bytes_written) << " MiB." << std::endl;
 
-  // Machine-readable summary (extends the reference's phase log).
-  const uint64_t pairs = cuking_submatrix_num_pairs(&sm);
+  const uint64_t pairs = cuking_submatrix_num_pairs(&job->sm);
+  const double kernel_seconds = job->kernel_seconds, read_pack_seconds = job->read_pack_seconds;
   const double rate = kernel_seconds > 0 ? pairs / kernel_seconds : 0;
-  std::cout << "{\"pairs\": " << pairs << ", \"triples\": " << num_triples.load()
+  const size_t num_triples = job->num_triples.load();
+  const PackerStats &packer_stats = job->packer_stats;
+  std::cout << "{\"pairs\": " << pairs << ", \"triples\": " << num_triples
             << ", \"results\": " << num_results << ", \"decode_thread_seconds\": "
-            << std::setprecision(3) << decode_us.load() * 1e-6
-            << ", \"pack_thread_seconds\": " << pack_us.load() * 1e-6
+            << std::setprecision(3) << job->decode_us.load() * 1e-6
+            << ", \"pack_thread_seconds\": " << job->pack_us.load() * 1e-6
             << ", \"device_pack_thread_seconds\": {\"setup\": "
             << packer_stats.setup_us.load() * 1e-6 << ", \"slot_wait\": "
             << packer_stats.wait_us.load() * 1e-6 << ", \"narrow\": "
             << packer_stats.narrow_us.load() * 1e-6 << ", \"enqueue\": "
             << packer_stats.enqueue_us.load() * 1e-6 << "}"
-            << ", \"pack\": \"" << (synthetic ? "synthetic" : pack_mode)
-            << "\", \"decode_tasks\": " << tasks.size() << ", \"reader_threads\": "
+            << ", \"pack\": \"" << (job->synthetic ? "synthetic" : job->pack_mode)
+            << "\", \"decode\": \"" << (flags.decode != "table" ? "stream" : "table")
+            << "\", \"decode_tasks\": " << job->tasks.size() << ", \"reader_threads\": "
             << flags.num_reader_threads << ", \"read_pack_seconds\": " << read_pack_seconds
             << ", \"triples_per_second\": " << std::setprecision(1)
-            << (read_pack_seconds > 0 ? num_triples.load() / read_pack_seconds : 0.0)
+            << (read_pack_seconds > 0 ? num_triples / read_pack_seconds : 0.0)
             << std::setprecision(3)
             << ", \"kernel_seconds\": "
             << std::setprecision(6) << kernel_seconds << ", \"pairs_per_second\": "
             << std::setprecision(1) << rate << ", \"algorithmic_GBps\": "
-            << rate * cuking_bytes_per_pair(words_per_sample) / 1e9
+            << rate * cuking_bytes_per_pair(job->words_per_sample) / 1e9
             << ", \"hbm_roofline_fraction\": " << std::setprecision(3)
-            << rate * cuking_bytes_per_pair(words_per_sample) / 8e12
+            << rate * cuking_bytes_per_pair(job->words_per_sample) / 8e12
             // what the five-product matrix-core form (king_mfma.hip, rounds 1-2: five
             // plane products per pair and site, 2 FLOP each) would have to sustain for
             // this rate; the default kernel (king_filter.hip) issues ONE product for
             // every pair and the exact sums for the pairs its bound admits, so this
             // may exceed the 10 PF the matrix cores have
-            << ", \"five_product_equivalent_PFLOPs\": " << rate * 10.0 * metadata.num_sites / 1e15
-            << multi_summary.str() << "}" << std::endl;
+            << ", \"five_product_equivalent_PFLOPs\": "
+            << rate * 10.0 * job->metadata.num_sites / 1e15
+            << job->multi_summary.str() << "}" << std::endl;
   return Status::Ok();
+}
+
+// cuking.cu:435-882, phase by phase: metadata -> Submatrix -> all-ones bitset -> parallel
+// Parquet decode + pack -> kernel -> overflow check -> sort -> Snappy Parquet.
+Status Run(const Flags &flags) {
+  Job job(flags);
+  RETURN_IF_ERROR(DescribeInput(&job));
+  if (flags.print_schedule) {  // host arithmetic only: no GPU, no input tables
+    PrintSchedule(flags, job.sm);
+    return Status::Ok();
+  }
+  RETURN_IF_ERROR(PlanInput(&job));
+  RETURN_IF_ERROR(AllocateBitSet(&job));
+  std::cout << (job.synthetic ? "Synthesising genotypes on the GPU..."
+                              : "Processing Parquet tables...")
+            << std::flush;
+  if (job.synthetic) RETURN_IF_ERROR(SynthesiseCohort(&job));
+  RETURN_IF_ERROR(DecodeAndPack(&job));
+  if (job.dump_only) return DumpBitSet(&job);
+  // (list -> decode -> pack -> bitset on the GPU; with --num_gpus and host pack
+  //  the upload belongs to the broadcast that follows)
+  job.read_pack_seconds = job.sw.ElapsedAndReset();
+  std::cout << " (" << std::fixed << std::setprecision(3) << job.read_pack_seconds << "s)"
+            << std::endl;
+  RETURN_IF_ERROR(job.multi_gpu ? ComputeOnSeveralGpus(&job) : ComputeOnOneGpu(&job));
+  return WriteOutput(&job);
 }
 
 }  // namespace

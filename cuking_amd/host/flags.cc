@@ -59,7 +59,7 @@ std::string Usage() {
          "smaller of --num_reader_threads and the hardware threads this process sees)\n"
          "  --decode=table|stream|auto  table: decode a whole table (or row group), then pack "
          "it; stream: pack batches of triples as they are decoded (no column-sized buffers); "
-         "default auto: stream for the host pack, table for the device pack\n"
+         "default auto = stream\n"
          "  --num_gpus=N           share the shard among N GPUs of this node over "
          "RCCL (default 0: one GPU, no RCCL)\n"
          "  --multi_gpu_mode=auto|staged|simple  broadcast overlapped with compute "

@@ -31,7 +31,7 @@ struct Flags {
   std::string decode = "auto";          // table: a whole table (or row group) decoded, then
                                         // packed; stream: batches of triples packed as they
                                         // are decoded (parquet_io.h StreamTriples); auto:
-                                        // stream for the host pack, table for the device pack
+                                        // stream
   size_t decode_batch = 0;              // test hook: triples per batch of --decode=stream
                                         // (0: 32 Ki for the host pack, a staging slot's
                                         // worth for the device pack)

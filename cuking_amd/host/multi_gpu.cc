@@ -268,6 +268,9 @@ void RankBody(Shared *sh, PhaseBarrier *barrier, int rank) {
   if (ok)
     RANK_ABI(cuking_ctx_set_kernel(st.ctx, tiled ? CUKING_KERNEL_TILED : CUKING_KERNEL_STREAM));
   if (ok) RANK_ABI(cuking_timing_enable(st.ctx, 1));
+  // (the staged schedule's rectangles cover every broadcast chunk in a union over the
+  //  ranks: the chunks may be laid out sorted by missing share, include/cuking_amd.h)
+  if (ok && tiled) RANK_ABI(cuking_ctx_set_option(st.ctx, "filter_sort", 2));
   if (ok) RANK_HIP(hipStreamCreateWithFlags(&st.comm, hipStreamNonBlocking));
   if (ok) RANK_HIP(hipStreamCreateWithFlags(&st.compute, hipStreamNonBlocking));
   if (ok) RANK_HIP(hipStreamCreateWithFlags(&st.copy, hipStreamNonBlocking));

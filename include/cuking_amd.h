@@ -281,7 +281,12 @@ uint32_t cuking_tile_samples(const cuking_ctx *ctx); /* samples per tile edge */
 /* Which tile of the block tile index `tile` is: rows [*row_begin, *row_end)
  * x columns [*col_begin, *col_end) in global sample indices (clamped to the
  * block).  Host-only; lets a scheduler reason about the samples a tile range
- * touches. */
+ * touches.  The bounds are in LAYOUT order: the default kernel lays a block's samples
+ * out sorted by their share of missing calls (option "filter_sort", default 1: whole-
+ * block conversions; samples of equal share -- an ordinary cohort: all of them -- keep
+ * their stored order), so in a cohort with low-call-rate samples the samples behind a
+ * tile are not the ones these bounds name; the union over all tiles is the block either
+ * way.  A caller that needs sample-accurate tiles sets "filter_sort" to 0. */
 cuking_status cuking_tile_bounds(const cuking_ctx *ctx,
                                  const cuking_submatrix *sm, uint64_t tile,
                                  uint32_t *row_begin, uint32_t *row_end,

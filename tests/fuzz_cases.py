@@ -112,7 +112,7 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
         # rigorous: off / automatic / an entry of the share menu), for bitsets of >= 4 k-steps
         chk0 = int(rng.choice([1, 0, 2, 2]))
         chk1 = int(rng.choice([1, 0, 3, 5, 7, 9]))
-        srt, lazy = int(rng.integers(0, 2)), int(rng.integers(0, 2))   # sorted layout, lazy codes
+        srt, lazy = int(rng.integers(0, 3)), int(rng.integers(0, 2))   # sorted layout, lazy codes
         if case < first_case:
             continue
         tag = dict(fuzzer="run_general", seed=seed, case=case, n=n, m=m, split_factor=k,

@@ -1293,9 +1293,10 @@ def test_filter_check_points_inside_the_k_loop(ctx, oracle, missing):
                     assert exits == 7, (thr, opts, exits)
                 if missing == 0.35 and opts.get("filter_check0") == 2 and whole and \
                         "max_launch_blocks" not in opts:
-                    # the bound thins nothing out: every tile leaves at the forecast (counted
-                    # as 4 quadrants each) and the fallback launch computes all of them
-                    assert dense == 4 * 15, (thr, opts, dense)
+                    # the bound thins nothing out: the tiles leave at the forecast (counted as 4
+                    # quadrants each; a tile of the ragged last column may stay under "three of
+                    # four quadrants dense") and the fallback launch computes all of them
+                    assert dense >= 4 * 10, (thr, opts, dense)
                 got = ctx.run(off, bits.shape[1], d_sub, thr, max_results=1 << 20)
                 assert got.tobytes() == e2.tobytes(), (thr, opts, "off-diagonal block")
     finally:
@@ -1331,7 +1332,7 @@ def test_filter_sorted_layout_and_lazy_codes(ctx, oracle):
     d_sub = ctx.upload_bitset(sub)
     dense = {}
     try:
-        for sort, lazy in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        for sort, lazy in ((1, 1), (0, 1), (2, 0), (0, 0)):
             ctx.set_option("filter_sort", sort)
             ctx.set_option("filter_lazy_codes", lazy)
             for reuse in (0, 1):
@@ -1345,7 +1346,7 @@ def test_filter_sorted_layout_and_lazy_codes(ctx, oracle):
                     got = ctx.run(sm, wps, d_bits, thr, max_results=1 << 20)
                     assert got.tobytes() == exp.tobytes(), (sort, lazy, reuse, thr, mode)
                     if (thr, mode, reuse) == (0.0884, 0, 0):
-                        dense[sort] = ctx.get_option("filter_dense_quadrants") - d0
+                        dense[min(sort, 1)] = ctx.get_option("filter_dense_quadrants") - d0
                     e2, _, _ = oracle.compute(oracle.submatrix(n, 2, 1), sub, thr, threads=16)
                     got = ctx.run(off, wps, d_sub, thr, max_results=1 << 20)
                     assert got.tobytes() == e2.tobytes(), (sort, lazy, reuse, thr, mode, "off-diagonal")

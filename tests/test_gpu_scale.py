@@ -152,7 +152,9 @@ def test_c3_300k_x_150k_whole_triangle_on_one_gpu(ctx, oracle):
     assert check_blocks(oracle, bits, res, thr, blocks) > 70_000
     # what 8 ranks would compute (equal contiguous tile ranges, cuking_amd.dist):
     # rank 5's share, from the same call the multi-GPU pass makes
+    # (tile bounds name samples only in an unsorted layout: include/cuking_amd.h)
     from cuking_amd.dist import tile_partition
+    ctx.set_option("filter_sort", 0)
     b, e = tile_partition(ctx.num_tiles(sm), 8)[5]
     part = ctx.run(sm, wps, bits, thr, max_results=4 << 20, tile_range=(b, e))
     lib, rb, re_, cb, ce = ctx.lib, *(C.c_uint32() for _ in range(4))
@@ -164,6 +166,7 @@ def test_c3_300k_x_150k_whole_triangle_on_one_gpu(ctx, oracle):
         check_blocks(oracle, bits, res, thr, [blk])
     keys = set(zip(part["sample_i"].tolist(), part["sample_j"].tolist()))
     assert keys <= set(zip(res["sample_i"].tolist(), res["sample_j"].tolist()))
+    ctx.set_option("filter_sort", 1)
     release(bits)
 
 
@@ -193,6 +196,7 @@ def test_c4_734k_x_200k_far_end_beyond_2_32_elements(ctx, oracle, c4):
     sm = cuking_amd.Submatrix(n)
     tiles, tile = ctx.num_tiles(sm), ctx.tile_samples()
     take = 150_000
+    ctx.set_option("filter_sort", 0)        # (tile bounds name samples only in an unsorted layout)
     res_hi = ctx.run(sm, wps, bits, thr, max_results=4 << 20, tile_range=(tiles - take, tiles))
     assert len(res_hi) > 1000
     rb, re_, cb, ce = (C.c_uint32() for _ in range(4))
@@ -204,6 +208,7 @@ def test_c4_734k_x_200k_far_end_beyond_2_32_elements(ctx, oracle, c4):
         seen += check_blocks(oracle, bits, res_hi, thr,
                              [((rb.value, re_.value), (cb.value, ce.value))])
     assert far >= 2 and seen > 40_000
+    ctx.set_option("filter_sort", 1)
     # far-corner rectangle through the staged operator
     lo = (n // tile - 20) * tile
     assert lo > first_far

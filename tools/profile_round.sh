@@ -8,14 +8,14 @@
 # pass only (the long configs[3] / configs[4] passes).
 # TRACE_STEPS / TRACE_WARMUP / PMC_STEPS override the step counts (defaults 20 / 3 / 2).
 set -eo pipefail
-TAG=${1:-r03}; shift || true
+TAG=${1:-r04}; shift || true
 LIGHT=0
 if [ "$1" = "--light" ]; then LIGHT=1; shift; fi
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-LEAN="--cpu-seconds 0 --extra-configs none --no-clock-pass"
+LEAN="--cpu-seconds 0 --extra-configs none --no-clock-pass --no-worst-case --no-h2d-pass"
 TS=${TRACE_STEPS:-20}; TW=${TRACE_WARMUP:-3}; PS=${PMC_STEPS:-2}
 echo "$TS $TW" > $OUT/trace_steps.txt
 if [ $LIGHT = 1 ]; then
