@@ -57,13 +57,22 @@ if trace:
             per_kernel.setdefault(short_name(r["Kernel_Name"]), []).append(
                 (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 durations = {}
+# passes of the profiled command: warm-up + timed steps, and (since round 4, unless
+# --reuse-layout) one more untimed + `steps` passes with the layout reused behind them
+trace_bench = {}
+try:
+    trace_bench = json.loads((src / "trace_bench.json").read_text())
+except Exception:
+    pass
+passes = steps + warmup + (steps + 1 if "value_layout_reused" in trace_bench else 0)
 for name, ms in per_kernel.items():
     # a pass that exceeds one launch's block limit goes out as several launches
     # (configs[4]: two): durations are per PASS
-    per_pass = max(1, round(len(ms) / (steps + warmup)))
+    per_pass = max(1, round(len(ms) / passes))
     if per_pass > 1 and len(ms) % per_pass == 0:
         ms = [sum(ms[k:k + per_pass]) for k in range(0, len(ms), per_pass)]
-    timed = ms[-steps:] if len(ms) > steps else ms      # (the warm-up launches come first)
+    # (the warm-up launches come first, the timed ones behind them)
+    timed = ms[warmup:warmup + steps] if len(ms) >= warmup + steps else ms
     durations[name] = {"launches": len(ms), "launches_per_pass": per_pass, "timed_launches": len(timed),
                        "median_ms": statistics.median(timed), "mean_timed_ms": statistics.fmean(timed),
                        "min_ms": min(ms), "max_ms": max(ms), "mean_all_ms": statistics.fmean(ms)}
@@ -122,11 +131,22 @@ table[f"{key}:{kernel}"] = entry
 # the block's bitset once and writes the kernel layout once
 wps = bench["roofline"].get("hbm", {}).get("algorithmic_bytes_per_pair", 0) // 16
 for name, d in durations.items():
+    if name.startswith("sample_stats_kernel"):
+        read = cfg["samples"] * wps * 8
+        gbps = read / (d["median_ms"] * 1e-3) / 1e9
+        table[f"{key}:{name}"] = {
+            "round": rnd, "kernel": name, "bound": "hbm", "median_ms": d["median_ms"],
+            "launches": d["launches"], "bytes_read": read, "bytes_written": 0,
+            "achieved_GBps": gbps, "peak_GBps": 8000.0, "frac": gbps / 8000.0,
+            "source": f"profiles/{rnd}_kernel_durations_{suffix}.json"}
     if name.startswith("prepare_"):
         read = cfg["samples"] * wps * 8
         # (bits per site and sample: the reference layout 2; nibble layout 4 + the het-only
         #  copy 1, and with <true> the two-bit T2 layout as well; word layout 4; quad layout 2)
-        write = (read * 7 // 2 if "nibbles_kernel<true>" in name else
+        if "nibbles_kernel<true, false>" in name and d["median_ms"] < 0.2:
+            continue     # (the gated conversion of the lazy codes: its workgroups left at once)
+        write = (read * 7 // 2 if ("nibbles_kernel<true>" in name or "<true, true>" in name) else
+                 read if "<false, true>" in name else       # T2 alone: 2 bits in, 2 bits out
                  read * 5 // 2 if "nibbles" in name else
                  read * (2 if "planes" in name else 1))
         gbps = (read + write) / (d["median_ms"] * 1e-3) / 1e9
