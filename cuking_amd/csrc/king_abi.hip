@@ -337,7 +337,7 @@ cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const Plan
   a->fsplit_parts = a->fsplit_first = a->fsplit_tile0 = 0;
   a->fsplit_slabs = nullptr;
   a->fsplit_tickets = nullptr;
-  a->wg_words = nullptr;
+  a->filter_totals = nullptr;
   a->tile_done = nullptr;
   a->prefix_u = nullptr;
   a->cohort_sums = nullptr;
@@ -369,7 +369,7 @@ cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const Plan
     ++ctx->workspace_allocations;
     // (the running totals behind "filter_candidates" / "filter_dense_quadrants")
     // ... and the tickets of the remainder pieces, zero between launches
-    hipError_t e = hipMemsetAsync(base, 0, kFilterCtrlBytes + kFilterTicketBytes, stream);
+    hipError_t e = hipMemsetAsync(base + want.totals, 0, kFilterCtrlBytes + kFilterTicketBytes, stream);
     if (e != hipSuccess) {
       (void)hipFree(base);
       HIP_TRY(e);
@@ -389,8 +389,8 @@ cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const Plan
   a->prefix_u = plane_prefix_u(ctx->planes, geo);
   a->cohort_sums = plane_cohort_sums(ctx->planes, geo);
   a->filter_ctrl = reinterpret_cast<uint32_t *>(base);
+  a->filter_totals = reinterpret_cast<unsigned long long *>(base + l.totals);
   a->fsplit_tickets = reinterpret_cast<uint32_t *>(base + l.tickets);
-  a->wg_words = reinterpret_cast<uint32_t *>(base + l.wg_words);
   a->tile_done = base + l.tile_done;
   a->cand_list = reinterpret_cast<uint2 *>(base + l.cand);
   a->cand_cap = ctx->filter_cand_cap < l.cand_entries ? ctx->filter_cand_cap : l.cand_entries;
@@ -1195,15 +1195,16 @@ cuking_status cuking_ctx_get_option(const cuking_ctx *ctx, const char *key,
     // Diagnostics (they WAIT for the device): pairs the bound let through, quadrants
     // handed to the exact kernel, and tiles that left at the rigorous check point, summed
     // over the context's streams, since the scratch was allocated.
-    const size_t word = strcmp(key, "filter_candidates") == 0        ? kCtrlTotalCand
-                        : strcmp(key, "filter_dense_quadrants") == 0 ? kCtrlTotalDense
-                                                                     : kCtrlTotalEarly;
+    const size_t word = strcmp(key, "filter_candidates") == 0        ? kTotalCand
+                        : strcmp(key, "filter_dense_quadrants") == 0 ? kTotalDense
+                                                                     : kTotalEarly;
     unsigned long long total = 0;
     if (hipSetDevice(ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
       return cuking_fail(CUKING_ERR_DEVICE, "device wait failed");
     for (auto &e : ctx->filter_scratch) {
       unsigned long long v = 0;
-      if (hipMemcpy(&v, e.base + word * 4, 8, hipMemcpyDeviceToHost) != hipSuccess)
+      if (hipMemcpy(&v, e.base + filter_scratch_layout(e.tiles).totals + word * 8, 8,
+                    hipMemcpyDeviceToHost) != hipSuccess)
         return cuking_fail(CUKING_ERR_DEVICE, "reading the filter counters failed");
       total += v;
     }

@@ -191,6 +191,7 @@ struct TiledArgs {
   const float2 *sample_stats;
   const uint4 *t2;         // the T2 layout (king_common.h, kLayoutNibbleStats)
   uint32_t *filter_ctrl;
+  unsigned long long *filter_totals;
   uint2 *cand_list;
   uint32_t cand_cap;       // entries of cand_list
   uint32_t quadrant_cap;   // candidates per quadrant beyond which it is "dense"
@@ -210,10 +211,9 @@ struct TiledArgs {
   // float per plane sample.  Check 1 is rigorous (every term of X is non-negative): a
   // tile none of whose pairs can still become a candidate leaves there.  Check 0
   // is a forecast (the bound scaled to the prefix) for short launches: a tile most
-  // of whose quadrants look dense leaves for the exact kernel at once.  One word
-  // per tile of the launch chunk (wg_words, zero at launch) carries the wavefronts'
-  // findings to one another; tile_done[t] = 1 tells the fallback launch that tile
-  // t of the chunk needs nothing more.
+  // of whose quadrants look dense leaves for the exact kernel at once.  The pipeline is
+  // drained at a check, so the wavefronts exchange their findings through LDS;
+  // tile_done[t] = 1 tells the fallback launch that tile t of the chunk needs nothing more.
   // check_steps[k] (device memory, written by the kernel that computed the prefix counts:
   // the two always agree): k-steps behind share k of kCheckShares64 (0 = bitset too short
   // for checks); prefix_u[k * s_stride + s]: u of plane sample s over those k-steps' sites.
@@ -224,7 +224,8 @@ struct TiledArgs {
   const float *prefix_u;
   const unsigned long long *cohort_sums;
   uint32_t check0, check1;  // switches (check1: 0 off, 1 automatic, 2 + k: entry k forced)
-  uint32_t *wg_words;
+  // one flag per tile of the launch chunk, directly behind the chunk's control words
+  // (filter_ctrl + kCtrlChunkBytes: one memset clears both in front of a chunk)
   uint8_t *tile_done;
   // Persistent mode of the four-product kernel (king_mfma.hip), the filter's
   // fallback: when *gate != 0, workgroup b of a fixed grid takes units b, b + grid,
@@ -357,12 +358,13 @@ constexpr size_t kFilterCtrlBytes = 256;
 // (list slots), 2 dynamic-tail counter, 3 quadrants finished, 4 quadrants of tiles that
 // left for the exact kernel at check 0, 5 "every remaining tile leaves" (most quadrants
 // so far went dense), 6 gate of the fallback launch (some tile left).  Running totals
-// since the scratch was allocated (u64 each): 16 candidates, 18 quadrants handed to the
-// exact kernel, 20 tiles that left at the rigorous check.
+// since the scratch was allocated (u64 each, behind the tile flags: TiledArgs::
+// filter_totals): 0 candidates, 1 quadrants handed to the exact kernel, 2 tiles that left
+// at the rigorous check.
 constexpr uint32_t kCtrlCand = 0, kCtrlDense = 1, kCtrlDyn = 2, kCtrlFinished = 3,
                    kCtrlLeft = 4, kCtrlAllLeave = 5, kCtrlGate = 6;
 constexpr size_t kCtrlChunkBytes = 32;
-constexpr uint32_t kCtrlTotalCand = 16, kCtrlTotalDense = 18, kCtrlTotalEarly = 20;
+constexpr uint32_t kTotalCand = 0, kTotalDense = 1, kTotalEarly = 2;
 __host__ __device__ inline const uint32_t *plane_check_steps(const uint4 *planes,
                                                              const PlaneGeometry &g) {
   return reinterpret_cast<const uint32_t *>(plane_cohort_sums(planes, g) + 8);
@@ -389,12 +391,13 @@ __host__ __device__ inline uint32_t *plane_sort_words(const uint4 *planes, const
 }
 constexpr uint32_t kNoSample = 0xFFFFFFFFu;
 
-// Scratch of one stream: control words, tickets, one word and one flag per tile of a
-// launch chunk, the candidate list, the dense-quadrant list, the remainder slabs.  The
-// lists are sized for the block the scratch serves (`tiles` 256-sample tiles in its
-// enumeration): 64 candidates per quadrant of a chunk, at most kFilterCandCap.
+// Scratch of one stream: the chunk's control words and one flag per tile of a launch chunk
+// (cleared together in front of every chunk), the running totals, tickets, the candidate
+// list, the dense-quadrant list, the remainder slabs.  The lists are sized for the block the
+// scratch serves (`tiles` 256-sample tiles in its enumeration): 64 candidates per quadrant
+// of a chunk, at most kFilterCandCap.
 struct FilterScratchLayout {
-  size_t tickets, wg_words, tile_done, cand, dense, slabs, bytes;
+  size_t tile_done, totals, tickets, cand, dense, slabs, bytes;
   uint32_t chunk_tiles, cand_entries;
 };
 inline FilterScratchLayout filter_scratch_layout(uint64_t tiles) {
@@ -403,10 +406,10 @@ inline FilterScratchLayout filter_scratch_layout(uint64_t tiles) {
   const uint64_t cand = (uint64_t)l.chunk_tiles * 4 * 64;
   l.cand_entries = (uint32_t)(cand < kFilterCandCap ? cand : kFilterCandCap);
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
-  l.tickets = kFilterCtrlBytes;
-  l.wg_words = l.tickets + kFilterTicketBytes;
-  l.tile_done = l.wg_words + up((size_t)l.chunk_tiles * sizeof(uint32_t));
-  l.cand = l.tile_done + up(l.chunk_tiles);
+  l.tile_done = kCtrlChunkBytes;
+  l.totals = up(l.tile_done + l.chunk_tiles);
+  l.tickets = l.totals + kFilterCtrlBytes;
+  l.cand = l.tickets + kFilterTicketBytes;
   l.dense = l.cand + up((size_t)l.cand_entries * sizeof(uint2));
   l.slabs = l.dense + up((size_t)l.chunk_tiles * 4 * sizeof(uint2));
   l.bytes = l.slabs + kFilterSplitSlabs * kFilterSlabBytes;

@@ -501,24 +501,39 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   // across it: ~8 us per check of a 500 us tile.
   uint32_t chk0 = 0, chk1 = 0, entry1 = 0;
   if (!CUKING_FILTER_FINE && !split && a.check_steps != nullptr && a.tile_done != nullptr) {
-    if (a.check0 != 0) chk0 = a.check_steps[0];
-    if (a.check1 >= 2) {
-      entry1 = a.check1 - 2;
-    } else if (a.check1 == 1) {
+    // kappa: the level of the bound for this cohort's unrelated pairs (from its mean missing
+    // and het rates) plus 4.6 standard deviations and a little
+    float kappa = -1.f;
+    {
       const float ns = (float)a.cohort_sums[0], nm = (float)a.cohort_sums[1],
                   nh = (float)a.cohort_sums[2];
       if (ns > 0.f && nh > 0.f) {
         const float sites = 256.f * (float)all_steps;
         const float m = nm / (ns * sites), h = nh / (ns * sites);
-        const float kappa =
-            m * (1.f + m / (2.f * h * (1.f - m))) + 4.6f * rsqrtf(sites) + 0.003f;
-        const float f64 = 64.f * (1.f - 2.f * a.kin_threshold) / (1.f - 2.f * kappa);
-        // (a check costs ~3 % of a tile -- the pipeline drained and refilled, the sweep:
-        //  entries that save less than 6 % of the k-steps are for tests only)
-#pragma unroll
-        for (uint32_t k = kNumCheckShares - 1; k >= 1; --k)
-          if ((float)kCheckShares64[k] >= f64 && kCheckShares64[k] <= 60) entry1 = k;
+        kappa = m * (1.f + m / (2.f * h * (1.f - m))) + 4.6f * rsqrtf(sites) + 0.003f;
       }
+    }
+    // Check 0 (the forecast; a.check0: 1 = this is a short launch, 2 = forced): only for a
+    // cohort whose unrelated pairs come anywhere near the threshold -- a drain and a sweep
+    // per tile (1.5-3 % of configs[1]) that a clean cohort need not pay; a cohort that is
+    // clean on average but holds a few bad samples then carries its dense tiles to their
+    // end before the quadrant lists take them over.
+    if (a.check0 == 2 || (a.check0 == 1 && kappa > 0.7f * a.kin_threshold))
+      chk0 = a.check_steps[0];
+    if (a.check1 >= 2) {
+      entry1 = a.check1 - 2;
+    } else if (a.check1 == 1 && kappa >= 0.f) {
+      const float f64 = 64.f * (1.f - 2.f * a.kin_threshold) / (1.f - 2.f * kappa);
+      // (a check costs a tile that leaves ~1.5 % -- the drain, the sweep -- and one that
+      //  stays ~3 % -- the refill as well: entries up to 60/64 are taken when the forecast
+      //  share reaches them, 61/64 only with half a step of margin to spare -- 200k sites
+      //  at threshold 0.05 --, the later ones are for tests)
+#pragma unroll
+      for (uint32_t k = kNumCheckShares - 1; k >= 1; --k)
+        if ((float)kCheckShares64[k] >= f64 &&
+            (kCheckShares64[k] <= 60 ||
+             (kCheckShares64[k] == 61 && (float)kCheckShares64[k] >= f64 + 0.5f)))
+          entry1 = k;
     }
     if (entry1 >= 1 && entry1 < kNumCheckShares) chk1 = a.check_steps[entry1];
     if (chk0 >= num_steps) chk0 = 0;
@@ -668,12 +683,12 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
         __hip_atomic_store(a.filter_ctrl + kCtrlGate, 1u, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(
-            reinterpret_cast<unsigned long long *>(a.filter_ctrl + kCtrlTotalDense), 4ull,
+            a.filter_totals + kTotalDense, 4ull,
             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {
         a.tile_done[bid] = 1;
         __hip_atomic_fetch_add(
-            reinterpret_cast<unsigned long long *>(a.filter_ctrl + kCtrlTotalEarly), 1ull,
+            a.filter_totals + kTotalEarly, 1ull,
             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
@@ -849,7 +864,7 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
           got = __hip_atomic_fetch_add(a.filter_ctrl, total, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
           // (running total since the scratch was allocated: "filter_candidates")
-          __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.filter_ctrl + kCtrlTotalCand),
+          __hip_atomic_fetch_add(a.filter_totals + kTotalCand,
                                  (unsigned long long)total, __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -866,7 +881,7 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
           const uint32_t slot = __hip_atomic_fetch_add(a.filter_ctrl + kCtrlDense, 1u, __ATOMIC_RELAXED,
                                                        __HIP_MEMORY_SCOPE_AGENT);
           if (slot < a.dense_cap) a.dense_list[slot] = make_uint2(2 * tr + wy, 2 * tc + wx);
-          __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.filter_ctrl + kCtrlTotalDense), 1ull,
+          __hip_atomic_fetch_add(a.filter_totals + kTotalDense, 1ull,
                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         break;
@@ -990,14 +1005,9 @@ hipError_t launch_filter(const TiledArgs &args, uint64_t num_tiles, hipStream_t 
   uint64_t done = 0;
   while (done < num_tiles) {
     const uint64_t n = num_tiles - done < cap ? num_tiles - done : cap;
-    hipError_t e = hipMemsetAsync(args.filter_ctrl, 0, kCtrlChunkBytes, stream);
-    if (e != hipSuccess) return e;
-    const bool checks = args.wg_words != nullptr && args.tile_done != nullptr;
-    if (checks) {
-      e = hipMemsetAsync(args.wg_words, 0, n * sizeof(uint32_t), stream);
-      if (e != hipSuccess) return e;
-      e = hipMemsetAsync(args.tile_done, 0, n, stream);
-    }
+    // (the chunk's control words and, directly behind them, its tile flags: one memset)
+    const bool checks = args.tile_done != nullptr;
+    hipError_t e = hipMemsetAsync(args.filter_ctrl, 0, kCtrlChunkBytes + (checks ? n : 0), stream);
     if (e != hipSuccess) return e;
     TiledArgs a = args;
     a.tile_begin = args.tile_begin + done;
@@ -1007,7 +1017,7 @@ hipError_t launch_filter(const TiledArgs &args, uint64_t num_tiles, hipStream_t 
     a.skip_tiles = nullptr;
     // check 0 (the forecast): for launches of fewer than 16 rounds, where the tiles that
     // would have to give up make up most of the launch before anybody has finished
-    a.check0 = checks && (args.check0 == 2 || (args.check0 == 1 && n < 16ull * wgs)) ? 1u : 0u;
+    a.check0 = !checks ? 0u : args.check0 == 2 ? 2u : (args.check0 == 1 && n < 16ull * wgs) ? 1u : 0u;
     a.check1 = checks ? args.check1 : 0u;
     // Short launches: the tiles beyond whole rounds of one per CU would leave most
     // CUs idle for a whole tile time; each of them is cut into `parts` pieces of k

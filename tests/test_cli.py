@@ -789,13 +789,11 @@ def test_hundred_million_triples_through_both_packs(tmp_path_factory):
     best, outputs = {}, {}
     for rep in range(2):
         for pack in ("host", "device"):
-            # (like with like: whole tables decoded, then packed, on both sides -- the host
-            #  pack's default is the streaming decode, the device pack's is not yet)
+            # (both packs with the default decode: batches packed as they are decoded)
             p = run_cli("--input_uri", d / "in", "--output_uri", d / f"out_{pack}", f"--pack={pack}",
-                        "--decode=table", "--num_reader_threads=16", "--kin_threshold=0.05",
-                        check=True)
+                        "--num_reader_threads=16", "--kin_threshold=0.05", check=True)
             s_ = json.loads(p.stdout.strip().splitlines()[-1])
-            assert s_["triples"] == triples and s_["pack"] == pack
+            assert s_["triples"] == triples and s_["pack"] == pack and s_["decode"] == "stream"
             assert s_["decode_tasks"] > files            # row groups, not files
             best[pack] = min(best.get(pack, 1e9), s_["read_pack_seconds"])
             if rep == 1:
@@ -806,10 +804,8 @@ def test_hundred_million_triples_through_both_packs(tmp_path_factory):
     print(f"1e8 triples: host pack {best['host']:.3f} s, device pack {best['device']:.3f} s")
     # At this size the device pack's set-up (page-locked rings, streams: ~0.12 s) is
     # not amortised; it must stay within that -- plus the noise of a shared box -- of the
-    # host pack (it overtakes it from about 5e8 triples on: profiles/r03_pack_pipeline.txt:
-    # 0.27-0.29 s against 0.19 s here).  0.20 since the host pack clears a word per sample
-    # and column instead of a bit per triple (0.66 -> ~0.25 of its 1.8 thread-seconds: the
-    # host side of this comparison got ~0.03 s faster, the device side did not change).
+    # host pack (profiles/r04_pack_pipeline.txt: 0.175 s against 0.069 s here with 16 reader
+    # threads; it overtakes the host pack near 1e9 triples).
     assert best["device"] <= best["host"] + 0.20, best
     # --pack=auto: the host pack for an input this small (0.2 GB of Parquet), at any
     # thread count
