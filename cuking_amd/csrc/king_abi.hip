@@ -118,13 +118,16 @@ struct cuking_ctx {
     uint64_t tiles;  // the block size (tiles of its enumeration) the lists are sized for
   };
   std::vector<FilterScratch> filter_scratch;
+  // The running totals of scratch blocks that have been freed since (a larger block took
+  // their place, their stream made room): the diagnostics count over the context's life.
+  unsigned long long filter_totals_retired[3] = {0, 0, 0};
   uint32_t filter_quadrant_cap = kFilterQuadrantCap;
   uint32_t filter_cand_cap = kFilterCandCap;
   uint32_t filter_split_min_steps = 8;  // k-steps per remainder piece, at least
   // Check points of the filter kernel (king_common.h): check 0 (forecast) 0 off, 1 for
   // launches of fewer than 16 rounds, 2 always; check 1 (rigorous) 0 off, 1 the entry the
   // kernel picks from threshold and cohort, 2 + k entry k of the share menu forced.
-  int filter_check0 = 1, filter_check1 = 1;
+  int filter_check0 = 1, filter_check1 = 1, filter_check_emit = (int)kCheckEmitCap;
   // The kernel layout's samples sorted by their share of missing calls (king_sort.hip);
   // the four-product kernel's codes converted only when the filter needs them
   // (0: with every conversion).
@@ -326,6 +329,19 @@ cuking_status split_scratch_for(cuking_ctx *ctx, hipStream_t stream,
 // when a larger block comes; the control words are zeroed by every launch chunk), or
 // nothing when the context's variant is not the filter variant.  Fills the filter
 // fields of `a`.
+// Before a scratch block is freed (nothing runs on its stream any more): its running totals
+// join the context's.
+static void retire_filter_totals(cuking_ctx *ctx, const cuking_ctx::FilterScratch &e) {
+  if (e.base == nullptr) return;
+  unsigned long long v[3] = {0, 0, 0};
+  if (hipMemcpy(v, e.base + filter_scratch_layout(e.tiles).totals, sizeof v,
+                hipMemcpyDeviceToHost) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  for (int k = 0; k < 3; ++k) ctx->filter_totals_retired[k] += v[k];
+}
+
 cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const PlaneGeometry &geo,
                                  uint64_t tiles, TiledArgs *a) {
   a->sample_stats = nullptr;
@@ -352,6 +368,7 @@ cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const Plan
     // a larger block: kernels of this stream may still use the old lists
     ++ctx->host_syncs;
     HIP_TRY(hipStreamSynchronize(stream));
+    retire_filter_totals(ctx, *entry);
     (void)hipFree(entry->base);
     entry->base = nullptr;
   }
@@ -361,6 +378,7 @@ cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const Plan
       ++ctx->host_syncs;
       HIP_TRY(hipStreamSynchronize(ctx->filter_scratch.front().stream));
       (void)hipGetLastError();  // (a stream its owner has destroyed meanwhile: nothing runs on it)
+      retire_filter_totals(ctx, ctx->filter_scratch.front());
       (void)hipFree(ctx->filter_scratch.front().base);
       ctx->filter_scratch.erase(ctx->filter_scratch.begin());
     }
@@ -401,7 +419,7 @@ cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const Plan
   a->fsplit_first = ctx->filter_split_min_steps;  // (on entry: launch_filter)
   a->fsplit_slabs = ctx->split_wgs != 0 ? reinterpret_cast<float4 *>(base + l.slabs) : nullptr;
   a->check0 = (uint32_t)ctx->filter_check0;  // (switches on entry: launch_filter)
-  a->check1 = (uint32_t)ctx->filter_check1;
+  a->check1 = (uint32_t)ctx->filter_check1 | ((uint32_t)ctx->filter_check_emit << 8);
   a->check_steps = plane_check_steps(ctx->planes, geo);
   return CUKING_OK;
 }
@@ -946,6 +964,12 @@ cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
     ctx->filter_check0 = (int)value;
     return CUKING_OK;
   }
+  if (strcmp(key, "filter_check_emit") == 0) {  // live pairs per quadrant handed over at the check
+    if (value < 0 || value > 255)
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "filter_check_emit outside [0, 255]");
+    ctx->filter_check_emit = (int)value;
+    return CUKING_OK;
+  }
   if (strcmp(key, "filter_check1") == 0) {  // rigorous check: 0 off, 1 automatic, 2 + k entry k
     if (value < 0 || value > 1 + (int64_t)kNumCheckShares || value == 2)
       return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "filter_check1 outside {0, 1, 3 .. %u}",
@@ -1190,11 +1214,12 @@ cuking_status cuking_ctx_get_option(const cuking_ctx *ctx, const char *key,
   else if (strcmp(key, "filter_lazy_codes") == 0) *value = ctx->filter_lazy_codes ? 1 : 0;
   else if (strcmp(key, "filter_check0") == 0) *value = ctx->filter_check0;
   else if (strcmp(key, "filter_check1") == 0) *value = ctx->filter_check1;
+  else if (strcmp(key, "filter_check_emit") == 0) *value = ctx->filter_check_emit;
   else if (strcmp(key, "filter_candidates") == 0 || strcmp(key, "filter_dense_quadrants") == 0 ||
            strcmp(key, "filter_early_exits") == 0) {
     // Diagnostics (they WAIT for the device): pairs the bound let through, quadrants
     // handed to the exact kernel, and tiles that left at the rigorous check point, summed
-    // over the context's streams, since the scratch was allocated.
+    // over the context's streams, since the context was created.
     const size_t word = strcmp(key, "filter_candidates") == 0        ? kTotalCand
                         : strcmp(key, "filter_dense_quadrants") == 0 ? kTotalDense
                                                                      : kTotalEarly;
@@ -1208,7 +1233,7 @@ cuking_status cuking_ctx_get_option(const cuking_ctx *ctx, const char *key,
         return cuking_fail(CUKING_ERR_DEVICE, "reading the filter counters failed");
       total += v;
     }
-    *value = (int64_t)total;
+    *value = (int64_t)(total + ctx->filter_totals_retired[word]);
   }
   else if (strcmp(key, "workspace_allocations") == 0) *value = (int64_t)ctx->workspace_allocations;
   else if (strcmp(key, "host_syncs") == 0) *value = (int64_t)ctx->host_syncs;
@@ -1503,8 +1528,12 @@ cuking_status cuking_ctx_reserve(cuking_ctx *ctx, const cuking_submatrix *sm,
       for (auto &e : ctx->filter_scratch) {
         bool named = false;
         for (size_t k = 0; k < num_streams; ++k) named = named || e.stream == (hipStream_t)streams[k];
-        if (named) keep.push_back(e);
-        else (void)hipFree(e.base);
+        if (named) {
+          keep.push_back(e);
+        } else {
+          retire_filter_totals(ctx, e);
+          (void)hipFree(e.base);
+        }
       }
       ctx->filter_scratch.swap(keep);
     }

@@ -223,7 +223,10 @@ struct TiledArgs {
   const uint32_t *check_steps;
   const float *prefix_u;
   const unsigned long long *cohort_sums;
-  uint32_t check0, check1;  // switches (check1: 0 off, 1 automatic, 2 + k: entry k forced)
+  // switches (check1, bits 0-7: 0 off, 1 automatic, 2 + k: entry k forced; bits 8-15: live
+  // pairs per quadrant up to which a tile that fails the rigorous check hands them to the
+  // candidate list and leaves anyway, kCheckEmitCap unless a test says otherwise)
+  uint32_t check0, check1;
   // one flag per tile of the launch chunk, directly behind the chunk's control words
   // (filter_ctrl + kCtrlChunkBytes: one memset clears both in front of a chunk)
   uint8_t *tile_done;
@@ -255,6 +258,9 @@ struct TiledArgs {
 // Prefix statistics: the k-steps (of 256 sites) a check may sit behind, as shares of the
 // bitset in 1/64ths -- the per-sample prefix counts are computed for every entry when
 // the layout is prepared, a launch picks the entries its threshold calls for.
+// Live pairs per quadrant a tile may hand to the candidate list at the rigorous check
+// (3.4 ns of recount each at 100k sites; the k-steps saved are ~50 us of a tile).
+constexpr uint32_t kCheckEmitCap = 64;
 constexpr uint32_t kNumCheckShares = 8;
 constexpr uint32_t kCheckShares64[kNumCheckShares] = {8, 50, 53, 56, 58, 60, 61, 62};
 // k-steps (of 256 sites) behind share k for a bitset of `all_steps` k-steps: even (the

@@ -184,7 +184,8 @@ __device__ __forceinline__ v8i tfrag(const uint4 w, uint32_t mask) {
 
 // Timing-only builds (wrong results, never shipped; tools/ab_flags.sh):
 // -DCUKING_FILTER_ABLATE=1 no LDS-DMA requests, =2 no stage barrier either,
-// =3 the shipped loop without the epilogue.
+// =3 the shipped loop without the epilogue, =4 the shipped kernel with every tile
+// reading tile (0, 0)'s operands.
 #ifndef CUKING_FILTER_ABLATE
 #define CUKING_FILTER_ABLATE 0
 #endif
@@ -298,8 +299,9 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
       split ? part * all_steps / a.fsplit_parts : 0u);
   const uint32_t num_steps = __builtin_amdgcn_readfirstlane(
       split ? (part + 1) * all_steps / a.fsplit_parts - k_first : all_steps);
-  const uint4 *g_rows = a.t2 + (uint64_t)tr * kT;
-  const uint4 *g_cols = a.t2 + a.geo.col_base + (uint64_t)tc * kT;
+  // (=4: every tile reads the operands of tile (0, 0) -- all requests hit the L2)
+  const uint4 *g_rows = a.t2 + (CUKING_FILTER_ABLATE == 4 ? 0u : (uint64_t)tr * kT);
+  const uint4 *g_cols = a.t2 + a.geo.col_base + (CUKING_FILTER_ABLATE == 4 ? 0u : (uint64_t)tc * kT);
 
   uint32_t mT;
   asm volatile("s_mov_b32 %0, 0xcccccccc" : "=s"(mT));
@@ -520,9 +522,10 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
     // end before the quadrant lists take them over.
     if (a.check0 == 2 || (a.check0 == 1 && kappa > 0.7f * a.kin_threshold))
       chk0 = a.check_steps[0];
-    if (a.check1 >= 2) {
-      entry1 = a.check1 - 2;
-    } else if (a.check1 == 1 && kappa >= 0.f) {
+    const uint32_t sw1 = a.check1 & 0xFFu;
+    if (sw1 >= 2) {
+      entry1 = sw1 - 2;
+    } else if (sw1 == 1 && kappa >= 0.f) {
       const float f64 = 64.f * (1.f - 2.f * a.kin_threshold) / (1.f - 2.f * kappa);
       // (a check costs a tile that leaves ~1.5 % -- the drain, the sweep -- and one that
       //  stays ~3 % -- the refill as well: entries up to 60/64 are taken when the forecast
@@ -544,7 +547,10 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   entry1 = __builtin_amdgcn_readfirstlane(entry1);
 
   uint32_t seg_first = 0;  // k-steps of the piece behind us
-  bool left = false, left_forecast = false;  // the tile left at a check point (uniform)
+  // the tile left at a check point (uniform): at the forecast, or at the rigorous check --
+  // with nothing alive, or with a few live pairs that the epilogue below (run on the prefix
+  // counts) hands to the candidate list
+  bool left = false, left_forecast = false, left_emit = false;
 #pragma nounroll
   while (true) {
     uint32_t seg_end = num_steps;
@@ -623,6 +629,7 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
       ck_cols[threadIdx.x] = make_float2(pu[ic], scale * fmaf(t, a.sample_stats[ic].y, 8.f));
     }
     __syncthreads();
+    const uint32_t emit_cap = a.check1 >> 8;  // (uniform; king_common.h check1)
     uint32_t cnt = 0;  // pairs of this lane still under the bound
     {
       float2 cc[4];
@@ -633,6 +640,9 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float2 cr = ck_rows[wy * 128 + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * g];
+          // (every element of the tile counts, the ones outside the block too: a tile on the
+          //  diagonal holds each sample against itself and stays -- 0.5 % of the tiles at
+          //  configs[2]; the test on the indices made the kernel a quarter longer)
 #pragma unroll
           for (int bj = 0; bj < 4; ++bj)
             cnt += fmaf(-0.5f, acc[bi][bj][r], cr.x + cc[bj].x) < fminf(cr.y, cc[bj].y) ? 1u : 0u;
@@ -644,18 +654,24 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
     //  of a quadrant scatters more widely than independent pairs would; at 7 % missing calls
     //  and the default threshold a sixth of the tiles left with the cap itself, for a launch
     //  the candidate list handles in half the time)
+    // (rigorous check: the word carries the quadrant's live pairs, capped -- a tile with
+    //  only a FEW of them, the relatives it holds, hands exactly those to the candidate list
+    //  and leaves as well: a cohort with some relatedness in every tile keeps its early exits)
     if (lane == 0)
-      ck_words[wave] = forecast ? (cnt > 2 * a.quadrant_cap ? 1u : 0u) : (cnt != 0 ? 1u : 0u);
+      ck_words[wave] = forecast ? (cnt > 2 * a.quadrant_cap ? 1u : 0u)
+                                : (cnt > emit_cap ? emit_cap + 1 : cnt);
     __syncthreads();
-    uint32_t found = ck_words[0] + ck_words[1] + ck_words[2] + ck_words[3];
+    uint32_t found = forecast ? ck_words[0] + ck_words[1] + ck_words[2] + ck_words[3]
+                              : max(max(ck_words[0], ck_words[1]), max(ck_words[2], ck_words[3]));
     found = __builtin_amdgcn_readfirstlane(found);
     __syncthreads();  // (the words are stage memory again from here on)
-    if (forecast ? found >= 3 : found == 0) {
+    if (forecast ? found >= 3 : found <= emit_cap) {
       // The tile leaves (uniform; nothing is in flight; the book-keeping follows behind
       // the loop: a divergent branch on the way out makes the compiler treat the whole
       // loop as divergent, request addresses and all).
       left = true;
       left_forecast = forecast;
+      left_emit = !forecast && found != 0;
       break;
     }
     seg_first = seg_end;
@@ -671,7 +687,10 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
 #undef F_PINF
 #undef F_READ
 #undef F_ISSUE4
-  if (left) {
+  if (left && left_emit && threadIdx.x == 0)
+    __hip_atomic_fetch_add(a.filter_totals + kTotalEarly, 1ull, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+  if (left && !left_emit) {
     // Forecast: the tile leaves for the exact kernel -- its quadrants count as handed
     // over, the fallback launch is needed.  Rigorous check: for good.
     if (threadIdx.x == 0) {
@@ -781,8 +800,18 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   float2 *const st_cols = st_rows + kT;
   {
     const float t = 2.f - 4.f * a.kin_threshold;
-    float2 r = a.sample_stats[(uint64_t)tr * kT + threadIdx.x];
-    float2 c = a.sample_stats[(uint64_t)a.geo.col_base + (uint64_t)tc * kT + threadIdx.x];
+    const size_t ir = (size_t)tr * kT + threadIdx.x;
+    const size_t ic = (size_t)a.geo.col_base + (size_t)tc * kT + threadIdx.x;
+    float2 r = a.sample_stats[ir];
+    float2 c = a.sample_stats[ic];
+    if (left_emit) {
+      // (the tile left at the rigorous check with a few live pairs: the same test on the
+      //  sums and the per-sample counts of the sites so far -- every record is among the
+      //  pairs it admits, king_filter.hip "Check points")
+      const float *const pu = a.prefix_u + (size_t)entry1 * s_stride;
+      r.x = pu[ir];
+      c.x = pu[ic];
+    }
     r.y = fmaf(t, r.y, 8.f);
     c.y = fmaf(t, c.y, 8.f);
     st_rows[threadIdx.x] = r;

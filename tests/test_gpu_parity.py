@@ -1237,7 +1237,8 @@ def test_filter_check_points_inside_the_k_loop(ctx, oracle, missing):
     """The filter kernel's check points (king_filter.hip): after a share of the k-steps a
     tile tests its sums against the bound over the sites so far.  The rigorous check lets a
     tile none of whose pairs can still become a candidate leave (every term of the
-    numerator's X is non-negative); the forecast at an eighth of the sites sends a tile whose
+    numerator's X is non-negative), and one with a FEW such pairs as well, handing them to
+    the candidate list as they stand; the forecast at an eighth of the sites sends a tile whose
     quadrants look dense to the exact kernel at once -- computed by the fallback launch
     (four-product kernel, persistent mode, gated on a device word) behind the filter
     kernel.  Every entry of the share menu forced, the forecast forced, both, neither, with
@@ -1250,6 +1251,9 @@ def test_filter_check_points_inside_the_k_loop(ctx, oracle, missing):
     for k in range(12):                        # a family inside one quadrant, relatives across tiles
         geno[300 + k] = np.where(rng.random(m) < 0.02, geno[5], geno[300])
     geno[n - 1], geno[700], geno[1023] = geno[2], geno[130], geno[256]
+    for k in range(9):                         # 81 related pairs in one quadrant of tile (0, 2)
+        geno[10 + k] = np.where(rng.random(m) < 0.02, geno[6], geno[10])
+        geno[520 + k] = np.where(rng.random(m) < 0.02, geno[7], geno[10])
     bits = oracle.bitset_from_genotypes(geno)
     d_bits = ctx.upload_bitset(bits)
     sm = cuking_amd.Submatrix(n)
@@ -1257,7 +1261,8 @@ def test_filter_check_points_inside_the_k_loop(ctx, oracle, missing):
     idx = list(range(off.i_begin, off.i_end)) + list(range(off.j_begin, off.j_end))
     sub = np.ascontiguousarray(bits[idx])
     d_sub = ctx.upload_bitset(sub)
-    defaults = {"filter_check0": 1, "filter_check1": 1, "filter_split_min_steps": 8,
+    defaults = {"filter_check0": 1, "filter_check1": 1, "filter_check_emit": 64,
+                "filter_split_min_steps": 8,
                 "max_launch_blocks": 0, "filter_quadrant_cap": 384, "split_wgs": 256}
     ctx.set_option("filter_check_min_steps", 4)
     try:
@@ -1275,6 +1280,8 @@ def test_filter_check_points_inside_the_k_loop(ctx, oracle, missing):
                      {"filter_check0": 2, "max_launch_blocks": 4, "split_wgs": 0}]
             cases += [{"filter_check0": 0, "filter_check1": 2 + k, "split_wgs": 0}
                       for k in range(1, 8)]
+            cases += [{"filter_check0": 0, "filter_check_emit": e, "split_wgs": 0}
+                      for e in (0, 1, 100)]
             for opts in cases:
                 for k, v in {**defaults, **opts}.items():
                     ctx.set_option(k, v)
@@ -1288,9 +1295,13 @@ def test_filter_check_points_inside_the_k_loop(ctx, oracle, missing):
                 if missing == 0.0 and thr == 0.2 and opts.get("filter_check1", 1) >= 3 and whole:
                     # unrelated samples sit near kinship 0: from ~0.7 of the sites on no pair of
                     # a tile without relatives can reach 0.2.  Of the 15 tiles the 5 on the
-                    # diagonal always hold a live pair (a sample against itself), 3 hold planted
-                    # duplicates -- (0, 2), (0, 4), (1, 3) --: the other 7 leave.
-                    assert exits == 7, (thr, opts, exits)
+                    # diagonal stay (each sample against itself is alive at any threshold) and
+                    # so does (0, 2) with 81 related pairs in one quadrant; (0, 4) and (1, 3)
+                    # hold one duplicate each: they hand it to the candidate list at the check
+                    # and leave with the 7 tiles that hold nothing.
+                    # (handing over switched off: those two stay; with a cap of 100, (0, 2) goes)
+                    emit = opts.get("filter_check_emit", 64)
+                    assert exits == (7 if emit == 0 else 10 if emit == 100 else 9), (thr, opts, exits)
                 if missing == 0.35 and opts.get("filter_check0") == 2 and whole and \
                         "max_launch_blocks" not in opts:
                     # the bound thins nothing out: the tiles leave at the forecast (counted as 4

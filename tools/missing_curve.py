@@ -7,7 +7,7 @@ every rate: kernel time per pass of both variants (HIP events around the whole c
 filter + refine + dense-quadrant kernels), candidates, dense quadrants -- and the records
 of the two variants compared byte for byte.
 
-usage: [MISSING_KS=0,3] python tools/missing_curve.py [samples] [sites] [threshold ...]
+usage: [MISSING_KS=0,3] [MISSING_HETERO=0.02,2] [MISSING_RELATED=0.25] python tools/missing_curve.py [samples] [sites] [threshold ...]
        -> gpurun_out/missing_curve.txt
 """
 import sys
@@ -146,6 +146,31 @@ def main():
                 if not same:
                     raise SystemExit("variants disagree")
         ctx.set_option("filter_sort", 1)
+        del bits
+    # The related cohort: a share of the samples are duplicates of samples elsewhere in the
+    # cohort, so that a good part of the TILES holds a record or two -- with and without the
+    # hand-over of a tile's few live pairs at the check point (king_filter.hip).
+    related = os.environ.get("MISSING_RELATED", "0.25")
+    if related:
+        pairs = int(n * float(related))
+        order = torch.randperm(n, device=base.device, generator=gen)
+        bits = base.clone()
+        bits[order[pairs:2 * pairs]] = base[order[:pairs]]
+        for thr in thrs:
+            ms6, r6, _ = run(ctx, 6, sm, wps, bits, thr)
+            for emit in (64, 0):
+                ctx.set_option("filter_check_emit", emit)
+                e0 = ctx.get_option("filter_early_exits")
+                ms7, r7, filt = run(ctx, 7, sm, wps, bits, thr)
+                exits = (ctx.get_option("filter_early_exits") - e0) / 6   # 1 warm-up + 5 passes
+                same = r7.tobytes() == r6.tobytes()
+                say(f"related: {pairs} duplicated samples at random places, hand-over cap {emit}, thr {thr} "
+                    f"variant 7 kernel_ms {ms7:.3f} variant 6 kernel_ms {ms6:.3f} records {len(r7)} "
+                    f"equal {same} candidates {filt[0]:.1f} tiles_left_at_the_check {exits:.0f} "
+                    f"of {ctx.num_tiles(sm)}")
+                if not same:
+                    raise SystemExit("variants disagree")
+        ctx.set_option("filter_check_emit", 64)
         del bits
     out.close()
 
