@@ -120,7 +120,7 @@ struct cuking_ctx {
   std::vector<FilterScratch> filter_scratch;
   // The running totals of scratch blocks that have been freed since (a larger block took
   // their place, their stream made room): the diagnostics count over the context's life.
-  unsigned long long filter_totals_retired[3] = {0, 0, 0};
+  unsigned long long filter_totals_retired[kNumTotals] = {};
   uint32_t filter_quadrant_cap = kFilterQuadrantCap;
   uint32_t filter_cand_cap = kFilterCandCap;
   uint32_t filter_split_min_steps = 8;  // k-steps per remainder piece, at least
@@ -128,6 +128,10 @@ struct cuking_ctx {
   // launches of fewer than 16 rounds, 2 always; check 1 (rigorous) 0 off, 1 the entry the
   // kernel picks from threshold and cohort, 2 + k entry k of the share menu forced.
   int filter_check0 = 1, filter_check1 = 1, filter_check_emit = (int)kCheckEmitCap;
+  // Rotated tiles (king_common.h TiledArgs::rotate): 0 off, 1 on, 2 / 3 + j test hooks;
+  // bitsets of fewer k-steps (of 256 sites) than the minimum are not rotated.
+  int filter_rotate = 1;
+  uint32_t filter_rotate_min_steps = 128;
   // The kernel layout's samples sorted by their share of missing calls (king_sort.hip);
   // the four-product kernel's codes converted only when the filter needs them
   // (0: with every conversion).
@@ -333,13 +337,13 @@ cuking_status split_scratch_for(cuking_ctx *ctx, hipStream_t stream,
 // join the context's.
 static void retire_filter_totals(cuking_ctx *ctx, const cuking_ctx::FilterScratch &e) {
   if (e.base == nullptr) return;
-  unsigned long long v[3] = {0, 0, 0};
+  unsigned long long v[kNumTotals] = {};
   if (hipMemcpy(v, e.base + filter_scratch_layout(e.tiles).totals, sizeof v,
                 hipMemcpyDeviceToHost) != hipSuccess) {
     (void)hipGetLastError();
     return;
   }
-  for (int k = 0; k < 3; ++k) ctx->filter_totals_retired[k] += v[k];
+  for (uint32_t k = 0; k < kNumTotals; ++k) ctx->filter_totals_retired[k] += v[k];
 }
 
 cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const PlaneGeometry &geo,
@@ -359,6 +363,7 @@ cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const Plan
   a->cohort_sums = nullptr;
   a->check_steps = nullptr;
   a->check0 = a->check1 = 0;
+  a->rotate = a->rotate_min_steps = 0;
   if (ctx->variant != kMfmaFilterVariant) return CUKING_OK;
   const FilterScratchLayout want = filter_scratch_layout(tiles);
   cuking_ctx::FilterScratch *entry = nullptr;
@@ -420,6 +425,8 @@ cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const Plan
   a->fsplit_slabs = ctx->split_wgs != 0 ? reinterpret_cast<float4 *>(base + l.slabs) : nullptr;
   a->check0 = (uint32_t)ctx->filter_check0;  // (switches on entry: launch_filter)
   a->check1 = (uint32_t)ctx->filter_check1 | ((uint32_t)ctx->filter_check_emit << 8);
+  a->rotate = (uint32_t)ctx->filter_rotate;
+  a->rotate_min_steps = ctx->filter_rotate_min_steps;
   a->check_steps = plane_check_steps(ctx->planes, geo);
   return CUKING_OK;
 }
@@ -964,6 +971,18 @@ cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
     ctx->filter_check0 = (int)value;
     return CUKING_OK;
   }
+  if (strcmp(key, "filter_rotate") == 0) {  // rotated tiles: 0 off, 1 on, 2 / 3 + phase: test hooks
+    if (value < 0 || value > 2 + (int64_t)kNumPhases)
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "filter_rotate outside [0, %u]", 2 + kNumPhases);
+    ctx->filter_rotate = (int)value;
+    return CUKING_OK;
+  }
+  if (strcmp(key, "filter_rotate_min_steps") == 0) {
+    if (value < 1 || value > (1 << 20))
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "filter_rotate_min_steps outside [1, 2^20]");
+    ctx->filter_rotate_min_steps = (uint32_t)value;
+    return CUKING_OK;
+  }
   if (strcmp(key, "filter_check_emit") == 0) {  // live pairs per quadrant handed over at the check
     if (value < 0 || value > 255)
       return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "filter_check_emit outside [0, 255]");
@@ -1215,14 +1234,17 @@ cuking_status cuking_ctx_get_option(const cuking_ctx *ctx, const char *key,
   else if (strcmp(key, "filter_check0") == 0) *value = ctx->filter_check0;
   else if (strcmp(key, "filter_check1") == 0) *value = ctx->filter_check1;
   else if (strcmp(key, "filter_check_emit") == 0) *value = ctx->filter_check_emit;
+  else if (strcmp(key, "filter_rotate") == 0) *value = ctx->filter_rotate;
+  else if (strcmp(key, "filter_rotate_min_steps") == 0) *value = ctx->filter_rotate_min_steps;
   else if (strcmp(key, "filter_candidates") == 0 || strcmp(key, "filter_dense_quadrants") == 0 ||
-           strcmp(key, "filter_early_exits") == 0) {
+           strcmp(key, "filter_early_exits") == 0 || strcmp(key, "filter_rotated_tiles") == 0) {
     // Diagnostics (they WAIT for the device): pairs the bound let through, quadrants
     // handed to the exact kernel, and tiles that left at the rigorous check point, summed
     // over the context's streams, since the context was created.
     const size_t word = strcmp(key, "filter_candidates") == 0        ? kTotalCand
                         : strcmp(key, "filter_dense_quadrants") == 0 ? kTotalDense
-                                                                     : kTotalEarly;
+                        : strcmp(key, "filter_early_exits") == 0     ? kTotalEarly
+                                                                     : kTotalRotated;
     unsigned long long total = 0;
     if (hipSetDevice(ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
       return cuking_fail(CUKING_ERR_DEVICE, "device wait failed");

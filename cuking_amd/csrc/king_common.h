@@ -214,9 +214,10 @@ struct TiledArgs {
   // of whose quadrants look dense leaves for the exact kernel at once.  The pipeline is
   // drained at a check, so the wavefronts exchange their findings through LDS;
   // tile_done[t] = 1 tells the fallback launch that tile t of the chunk needs nothing more.
-  // check_steps[k] (device memory, written by the kernel that computed the prefix counts:
-  // the two always agree): k-steps behind share k of kCheckShares64 (0 = bitset too short
-  // for checks); prefix_u[k * s_stride + s]: u of plane sample s over those k-steps' sites.
+  // check_steps[k] (device memory, written by the kernel that computed the counts): k-steps
+  // behind share k of kCheckShares64 from the first site on (0 = bitset too short for
+  // checks); prefix_u[(x - 1) * s_stride + s]: u of plane sample s over the k-steps in front
+  // of phase boundary x = 1 .. 63 (king_common.h phase_step).
   // Entry 0 is the forecast's (used when check0 != 0: short launches), entries 1 .. the
   // rigorous check's: every workgroup picks the same one from the threshold and the
   // cohort's mean missing and het rates (cohort_sums: samples, missing calls, het calls).
@@ -227,6 +228,12 @@ struct TiledArgs {
   // pairs per quadrant up to which a tile that fails the rigorous check hands them to the
   // candidate list and leaves anyway, kCheckEmitCap unless a test says otherwise)
   uint32_t check0, check1;
+  // Rotated tiles (king_filter.hip): 0 every tile starts at its first k-step; 1 a whole tile
+  // with check points starts at the phase boundary the other tiles of its XCD are at
+  // (filter_ctrl + kCtrlPos: one position word per XCD) and wraps around; 2 test hook: a
+  // phase drawn from the tile's index; 3 + j test hook: phase j.  rotate_min_steps: bitsets
+  // of fewer k-steps are not rotated.
+  uint32_t rotate, rotate_min_steps;
   // one flag per tile of the launch chunk, directly behind the chunk's control words
   // (filter_ctrl + kCtrlChunkBytes: one memset clears both in front of a chunk)
   uint8_t *tile_done;
@@ -263,12 +270,22 @@ struct TiledArgs {
 constexpr uint32_t kCheckEmitCap = 64;
 constexpr uint32_t kNumCheckShares = 8;
 constexpr uint32_t kCheckShares64[kNumCheckShares] = {8, 50, 53, 56, 58, 60, 61, 62};
-// k-steps (of 256 sites) behind share k for a bitset of `all_steps` k-steps: even (the
-// k loop runs two k-steps per trip), 0 when the bitset is too short for a check to pay.
+// The k-steps of a bitset in 64 PHASES: phase x is k-steps [phase_step(x), phase_step(x + 1)).
+// A tile may start its k loop at any phase boundary and wrap around (king_filter.hip,
+// "Rotated tiles": the tiles an XCD holds at a time read the same k-steps at the same time,
+// whenever each of them started), so the per-sample prefix counts are kept CUMULATIVE at
+// every phase boundary: u over phases [a, b) is the difference of two of them.
+constexpr uint32_t kNumPhases = 64;
+constexpr uint32_t kNumCum = kNumPhases - 1;  // boundaries 1 .. 63 (0 is zero, 64 the total)
+__host__ __device__ inline uint32_t phase_step(uint32_t all_steps, uint32_t x) {
+  return (uint32_t)((uint64_t)all_steps * x / kNumPhases);
+}
+// k-steps (of 256 sites) behind share k for a bitset of `all_steps` k-steps, counted from
+// the bitset's first site; 0 when the bitset is too short for a check to pay.
 __host__ __device__ inline uint32_t check_step_of(uint32_t all_steps, uint32_t k,
                                                   uint32_t min_steps = 64) {
   if (all_steps < min_steps) return 0;
-  return (uint32_t)((uint64_t)all_steps * kCheckShares64[k] / 64) & ~1u;
+  return phase_step(all_steps, kCheckShares64[k]);
 }
 // Remainder splitting: at most this many pieces per launch (one per CU), a slab of
 // 256 x 256 float sums and a ticket word each.
@@ -284,9 +301,9 @@ __host__ __device__ inline size_t plane_bytes(const PlaneGeometry &g,
   if (layout == kLayoutNibble) return base + base / 4;  // + the het-only copy
   if (layout == kLayoutNibbleStats)
     return base + base / 4 + base / 2 + (size_t)g.s_stride * sizeof(float2) +
-           (size_t)g.s_stride * kNumCheckShares * sizeof(float) + 64 + 64 +
+           (size_t)g.s_stride * kNumCum * sizeof(float) + 64 + 64 +
            // control block, perm, statistics before the sort, the sort's four arrays
-           64 + (size_t)g.s_stride * (4 + 8 + 4 * kNumCheckShares + 16);
+           64 + (size_t)g.s_stride * (4 + 8 + 4 * kNumCum + 16);
   return base;
 }
 // Where the T2 layout and the per-sample statistics of kLayoutNibbleStats start
@@ -297,7 +314,7 @@ __host__ __device__ inline const uint4 *plane_t2(const uint4 *planes, const Plan
 __host__ __device__ inline const float2 *plane_stats(const uint4 *planes, const PlaneGeometry &g) {
   return reinterpret_cast<const float2 *>(planes + (size_t)g.k_words * g.s_stride * 7 / 4);
 }
-// ... behind them the prefix counts (kNumCheckShares x s_stride floats) and the cohort's
+// ... behind them the cumulative counts (kNumCum x s_stride floats) and the cohort's
 // sums (three u64: samples counted, missing calls, het calls; s_stride is a multiple of
 // the tile edge, so everything stays 16-byte aligned), then the k-steps behind each share
 // as the prefix counts were computed for (kNumCheckShares u32).
@@ -307,7 +324,7 @@ __host__ __device__ inline const float *plane_prefix_u(const uint4 *planes, cons
 __host__ __device__ inline const unsigned long long *plane_cohort_sums(const uint4 *planes,
                                                                        const PlaneGeometry &g) {
   return reinterpret_cast<const unsigned long long *>(plane_prefix_u(planes, g) +
-                                                      (size_t)g.s_stride * kNumCheckShares);
+                                                      (size_t)g.s_stride * kNumCum);
 }
 
 // One compiled shape of the tiled kernel.
@@ -366,18 +383,26 @@ constexpr size_t kFilterCtrlBytes = 256;
 // so far went dense), 6 gate of the fallback launch (some tile left).  Running totals
 // since the scratch was allocated (u64 each, behind the tile flags: TiledArgs::
 // filter_totals): 0 candidates, 1 quadrants handed to the exact kernel, 2 tiles that left
-// at the rigorous check.
+// at the rigorous check, 3 tiles that started at another phase than the first.
 constexpr uint32_t kCtrlCand = 0, kCtrlDense = 1, kCtrlDyn = 2, kCtrlFinished = 3,
                    kCtrlLeft = 4, kCtrlAllLeave = 5, kCtrlGate = 6;
-constexpr size_t kCtrlChunkBytes = 32;
-constexpr uint32_t kTotalCand = 0, kTotalDense = 1, kTotalEarly = 2;
+// ... and where the tiles of each XCD are (rotated tiles, king_filter.hip): word 8 + x: the
+// 100 MHz counter's ticks per k-step x 16 as a tile of XCD x last measured them; from byte
+// 64 on, per XCD kPosSlots u64 = (k-step, counted on through the tiles, a tile of the XCD
+// had reached) << 32 | (when: low word of that counter) -- a tile writes slot (its
+// workgroup's turn on the XCD) mod kPosSlots at its segment ends, a new tile joins the most
+// advanced of them.
+constexpr uint32_t kCtrlStepTicks = 8, kCtrlPos = 16, kPosSlots = 16;
+constexpr size_t kCtrlChunkBytes = 64 + 8 * kPosSlots * 8;
+constexpr uint32_t kTotalCand = 0, kTotalDense = 1, kTotalEarly = 2, kTotalRotated = 3;
+constexpr uint32_t kNumTotals = 4;
 __host__ __device__ inline const uint32_t *plane_check_steps(const uint4 *planes,
                                                              const PlaneGeometry &g) {
   return reinterpret_cast<const uint32_t *>(plane_cohort_sums(planes, g) + 8);
 }
 // ... one control block (16 u32; word 0: codes_ready), then the sample order and what
 // building it needs, every array s_stride entries long: perm (u32), the statistics in
-// stored order before the sort (float2, then kNumCheckShares floats), keys in / out and
+// stored order before the sort (float2, then kNumCum floats), keys in / out and
 // values in / out of the sort (u32 each).
 __host__ __device__ inline uint32_t *plane_flags(const uint4 *planes, const PlaneGeometry &g) {
   return const_cast<uint32_t *>(plane_check_steps(planes, g)) + 16;
@@ -393,7 +418,7 @@ __host__ __device__ inline float *plane_tmp_prefix(const uint4 *planes, const Pl
 }
 __host__ __device__ inline uint32_t *plane_sort_words(const uint4 *planes, const PlaneGeometry &g) {
   return reinterpret_cast<uint32_t *>(plane_tmp_prefix(planes, g) +
-                                      (size_t)g.s_stride * kNumCheckShares);
+                                      (size_t)g.s_stride * kNumCum);
 }
 constexpr uint32_t kNoSample = 0xFFFFFFFFu;
 

@@ -91,71 +91,82 @@ __device__ __forceinline__ uint32_t source_sample(const PlaneGeometry &geo, uint
 
 // One wavefront per plane sample: (|Y| - |M|, |H|) as floats (exact below 2^24
 // sites).  Padding sites of the last word are missing (cuking.cu:513-523) and
-// count as such; padding samples get (0, 0).  Beside them the same |Y| - |M| over
-// the site prefixes the kernel's check points may sit behind (prefix[k][sample]:
-// the first 256 check_steps[k] sites = 4 check_steps[k] words of 64), and the
-// cohort's sums (samples, missing calls, het calls) the kernel picks a check from.
+// count as such; padding samples get (0, 0).  Beside them the same |Y| - |M|
+// CUMULATIVE at every phase boundary of the k-steps (king_common.h phase_step:
+// cum[x - 1][sample] = over the first 256 phase_step(x) sites, x = 1 .. 63) -- what a
+// check point of a tile that started at any phase needs --, and the cohort's sums
+// (samples, missing calls, het calls) the kernel picks a check from.
 struct CheckWords {
-  uint32_t w[kNumCheckShares];  // 64-bit words behind each share (0: no such check)
+  uint32_t w[kNumCheckShares];  // k-steps behind each share from the first site on (0: no checks)
 };
+constexpr uint32_t kStatsMaxSteps = kMfmaN4MaxSites / 256;  // k-steps of the widest bitset
 __global__ __launch_bounds__(256) void sample_stats_kernel(
     const uint64_t *__restrict__ bits, uint32_t words_per_sample, PlaneGeometry geo,
-    float2 *__restrict__ stats, float *__restrict__ prefix, unsigned long long *__restrict__ sums,
+    float2 *__restrict__ stats, float *__restrict__ cum, unsigned long long *__restrict__ sums,
     uint32_t *__restrict__ steps_out, CheckWords cw, uint32_t s_begin, uint32_t s_end) {
-  const uint32_t lane = threadIdx.x & 63;
-  if (blockIdx.x == 0 && threadIdx.x < kNumCheckShares) steps_out[threadIdx.x] = cw.w[threadIdx.x] / 4;
-  const uint32_t ps = s_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ uint8_t phase_of[kStatsMaxSteps];  // the phase a k-step belongs to
+  __shared__ int32_t phase_sum[4][kNumPhases];  // per wavefront: |Y| - |M| per phase
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && threadIdx.x < kNumCheckShares) steps_out[threadIdx.x] = cw.w[threadIdx.x];
+  const uint32_t all_steps = geo.k_words / 8;  // k-steps of 256 sites
+  // k-step s is in phase x <=> phase_step(x) <= s < phase_step(x + 1)
+  //                        <=> x = ceil(64 (s + 1) / all_steps) - 1
+  for (uint32_t st = threadIdx.x; st < all_steps; st += 256) {
+    const uint32_t x = (kNumPhases * (st + 1) - 1) / all_steps;
+    phase_of[st] = (uint8_t)(x < kNumPhases ? x : kNumPhases - 1);
+  }
+  phase_sum[wave][lane] = 0;
+  __syncthreads();
+  const uint32_t ps = s_begin + blockIdx.x * 4 + wave;
   if (ps >= s_end) return;  // whole wavefront
   const uint32_t src = source_sample(geo, ps);
   int32_t yc = 0, mc = 0, hc = 0;
-  int32_t pc[kNumCheckShares] = {};
   if (src != kNoPair) {
     const uint32_t n = words_per_sample / 2;
     const uint64_t *het = bits + (uint64_t)src * words_per_sample;
     const uint64_t *hom = het + n;
     constexpr uint32_t kAhead = 4;  // words per lane and plane requested before any is counted
-    // The words in the order of the share menu's boundaries (ascending): segment c ends
-    // where share c does, and the running |Y| - |M| at its end is that prefix's count --
-    // no per-word comparison against eight boundaries.
-    uint32_t seg_begin = 0;
+    for (uint32_t w0 = 0; w0 < n; w0 += 64 * kAhead) {
+      uint64_t h[kAhead], v[kAhead];
 #pragma unroll
-    for (uint32_t c = 0; c <= kNumCheckShares; ++c) {
-      uint32_t seg_end = c < kNumCheckShares ? cw.w[c] : n;
-      if (seg_end > n) seg_end = n;
-      if (seg_end < seg_begin) seg_end = seg_begin;  // (a share without a check: 0 words)
-      for (uint32_t w0 = seg_begin; w0 < seg_end; w0 += 64 * kAhead) {
-        uint64_t h[kAhead], v[kAhead];
+      for (uint32_t k = 0; k < kAhead; ++k) {
+        const uint32_t w = w0 + 64 * k + lane;
+        const bool in = w < n;
+        h[k] = in ? het[w] : 0ull;
+        v[k] = in ? hom[w] : 0ull;
+      }
 #pragma unroll
-        for (uint32_t k = 0; k < kAhead; ++k) {
-          const uint32_t w = w0 + 64 * k + lane;
-          const bool in = w < seg_end;
-          h[k] = in ? het[w] : 0ull;
-          v[k] = in ? hom[w] : 0ull;
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < kAhead; ++k) {
-          const bool in = w0 + 64 * k + lane < seg_end;  // beyond the segment: contributes nothing
-          yc += in ? __popcll(~h[k]) : 0;  // homozygous and defined (missing has the het bit set)
-          mc += __popcll(h[k] & v[k]);     // missing
-          hc += __popcll(h[k] & ~v[k]);    // het
+      for (uint32_t k = 0; k < kAhead; ++k) {
+        const uint32_t w = w0 + 64 * k + lane;
+        if (w < n) {  // (beyond the plane: contributes nothing)
+          const int32_t y = __popcll(~h[k]);    // homozygous and defined (missing has the het bit set)
+          const int32_t m = __popcll(h[k] & v[k]);  // missing
+          yc += y;
+          mc += m;
+          hc += __popcll(h[k] & ~v[k]);  // het
+          // (a k-step is 4 words of 64 sites; ~24 lanes share a phase: LDS adds)
+          atomicAdd(&phase_sum[wave][phase_of[w >> 2]], y - m);
         }
       }
-      if (c < kNumCheckShares) pc[c] = yc - mc;  // (this lane's share; summed over the lanes below)
-      seg_begin = seg_end;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       yc += __shfl_xor(yc, off);
       mc += __shfl_xor(mc, off);
       hc += __shfl_xor(hc, off);
-#pragma unroll
-      for (uint32_t c = 0; c < kNumCheckShares; ++c) pc[c] += __shfl_xor(pc[c], off);
     }
   }
+  // (the wavefront's own LDS adds are done: same wavefront, in order) inclusive scan over
+  // the phases: lane x holds the count in front of boundary x + 1
+  int32_t run = phase_sum[wave][lane];
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int32_t up = __shfl_up(run, off);
+    if ((int)lane >= off) run += up;
+  }
+  if (lane < kNumCum) cum[(size_t)lane * geo.s_stride + ps] = (float)run;
   if (lane == 0) {
     stats[ps] = make_float2((float)(yc - mc), (float)hc);
-#pragma unroll
-    for (uint32_t c = 0; c < kNumCheckShares; ++c) prefix[(size_t)c * geo.s_stride + ps] = (float)pc[c];
     // (the cohort's sums feed a choice, not a result: a sample of the samples will do --
     //  three device-scope atomics on three addresses for EVERY sample cost 3 ms at 100k)
     if (src != kNoPair && ((blockIdx.x & 15) == 0 || gridDim.x < 64)) {
@@ -255,9 +266,14 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   // over the chunk in its own order, king_mfma.hip persistent mode) computes every tile
   // that has not set its tile_done flag.  The worst case costs the exact kernel's time
   // plus the first round of this one (short launches: plus an eighth of it, check 0).
+// (A/B: k-steps a new tile starts ahead of where the tiles of its XCD are)
+#ifndef CUKING_ROTATE_LEAD
+#define CUKING_ROTATE_LEAD 0
+#endif
 #ifndef CUKING_FILTER_GIVE_UP
 #define CUKING_FILTER_GIVE_UP 1  // (A/B: 0 = tiles never give up)
 #endif
+  uint32_t xcd_pos = 0;  // the k-step the tiles of this XCD are at (rotated tiles)
   if (CUKING_FILTER_GIVE_UP && !split && a.tile_done != nullptr) {
     // ONE decision per workgroup (the counters move while the wavefronts read them,
     // and a wavefront that left alone would take its quarter of every stage's
@@ -280,13 +296,35 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
                              __HIP_MEMORY_SCOPE_AGENT);
         }
       }
-      *verdict = leave;
+      verdict[0] = leave;
+    }
+    // Rotated tiles (below): where the tiles of this XCD are -- workgroups go to the XCDs
+    // round-robin by their index.  Every slot says where one of them was and when; brought
+    // forward to now by the measured k-step time, the most advanced one counts.
+    if (a.rotate == 1 && threadIdx.x < kPosSlots) {
+      const uint32_t x = blockIdx.x & 7;
+      const unsigned long long said = __hip_atomic_load(
+          reinterpret_cast<const unsigned long long *>(a.filter_ctrl + kCtrlPos) + x * kPosSlots +
+              threadIdx.x,
+          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t ticks16 = __hip_atomic_load(a.filter_ctrl + kCtrlStepTicks + x,
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t pos = (uint32_t)(said >> 32);
+      const uint32_t ago = (uint32_t)__builtin_amdgcn_s_memrealtime() - (uint32_t)said;
+      if (said != 0 && ticks16 != 0 && ago < 16384u)
+        pos += ago * 16u / ticks16 + CUKING_ROTATE_LEAD;
+      verdict[1 + threadIdx.x] = pos;
     }
     __syncthreads();
-    const bool give_up = *verdict != 0;
-    __syncthreads();  // the word is stage memory from here on
+    const bool give_up = verdict[0] != 0;
+    if (a.rotate == 1) {
+#pragma unroll
+      for (uint32_t k = 0; k < kPosSlots; ++k) xcd_pos = max(xcd_pos, verdict[1 + k]);
+    }
+    __syncthreads();  // the words are stage memory from here on
     if (give_up) return;  // uniform across the workgroup; tile_done stays 0
   }
+  xcd_pos = __builtin_amdgcn_readfirstlane(xcd_pos);
   const uint32_t g = lane >> 5;                  // k-half of the MFMA operand
   const uint32_t lr = lane & 31;                 // row / column inside a block
   uint32_t lane16 = lane * 16;
@@ -324,18 +362,24 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   // of the segment, `seg_steps` its k-steps.
   const char *seg_src = g_wave;
   uint32_t seg_steps = num_steps;
+  // (a rotated tile, below: k-step `seg_wrap` of the segment is the bitset's FIRST again --
+  //  all_steps k-steps back; 32-bit scalar selects and one signed product: a select between
+  //  two 64-bit addresses goes through vector registers, which the scalar pins cannot take)
+  uint32_t seg_wrap = 0xFFFFFFFFu;
   auto addr_of = [&](uint32_t step, uint32_t buf) {
     Addr pa;
     if (step >= seg_steps) step = seg_steps - 1;  // clamped repeats (see king_mfma.hip)
-    pa.src = seg_src + (uint64_t)step * kstep_bytes;
+    const int32_t rel = (int32_t)step - (int32_t)(step >= seg_wrap ? all_steps : 0u);
+    pa.src = seg_src + (int64_t)rel * (int64_t)kstep_bytes;
     pa.dst = l_wave + buf * (kStageU4 * 16);
     asm volatile("" : "+s"(pa.src), "+s"(pa.dst));
     return pa;
   };
   auto addr_next = [&](const Addr &cur, uint32_t step, uint32_t buf) {
     Addr pa;
-    const uint32_t adv = step < seg_steps ? kstep_bytes : 0u;
-    pa.src = cur.src + adv;
+    const int32_t adv = (int32_t)(step < seg_steps ? 1u : 0u) -
+                        (int32_t)(step == seg_wrap ? all_steps : 0u);
+    pa.src = cur.src + (int64_t)adv * (int64_t)kstep_bytes;
     pa.dst = l_wave + buf * (kStageU4 * 16);
     asm volatile("" : "+s"(pa.src), "+s"(pa.dst));
     return pa;
@@ -501,8 +545,42 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   // behind it starts like a tile -- so that the check has the LDS for its per-sample
   // values and the register file for its sweep, and the k loop's registers are not live
   // across it: ~8 us per check of a 500 us tile.
-  uint32_t chk0 = 0, chk1 = 0, entry1 = 0;
+  //
+  // --- Rotated tiles.  The 32 tiles an XCD holds at a time are a patch of the tile space
+  // (8 rows x 4 columns: 12 strips of operands for 32 tiles), but they share those strips
+  // through the XCD's 4 MiB L2 only while they read the same k-steps at about the same
+  // time -- 21 k-steps of the patch fit.  Tiles that all start at k-step 0 do so in the
+  // first round of a launch and drift apart from there (L2 hit rate 0.36, 555 GB from the
+  // fabric per pass of configs[2]; one launch per round: 0.80 and 170 GB, and the chip
+  // holds 1.96-1.99 GHz instead of 1.86: tools/l2_probe.sh).  The order of the sites
+  // inside a sum does not matter, so a tile STARTS where the tiles of its XCD are: at the
+  // phase boundary (king_common.h phase_step: 64 phases) nearest to the k-step the most
+  // advanced of them has published, runs to the end of the sites, wraps around (a segment
+  // boundary like a check point's) and ends where it started.  A check point sits behind a
+  // share of the k-steps as before; the per-sample counts over "phases [p, p + e)" are
+  // differences of the cumulative counts sample_stats_kernel leaves.
+  uint32_t chk0 = 0, chk1 = 0, entry1 = 0, share1 = 0;
+  uint32_t phase = 0, k0 = 0, wrap = 0, start_abs = 0;
   if (!CUKING_FILTER_FINE && !split && a.check_steps != nullptr && a.tile_done != nullptr) {
+    if (a.rotate != 0 && all_steps >= a.rotate_min_steps) {
+      uint32_t base = 0;
+      if (a.rotate == 1) {
+        const uint32_t r = xcd_pos % all_steps;
+        base = xcd_pos - r;
+        phase = (r * kNumPhases + all_steps / 2) / all_steps;
+        if (phase >= kNumPhases) {
+          phase = 0;
+          base += all_steps;
+        }
+      } else if (a.rotate == 2) {
+        phase = (bid * 37u + 11u) & (kNumPhases - 1);  // (test hook)
+      } else {
+        phase = (a.rotate - 3u) & (kNumPhases - 1);    // (test hook)
+      }
+      k0 = phase_step(all_steps, phase);
+      start_abs = base + k0;
+      wrap = k0 != 0 ? all_steps - k0 : 0u;
+    }
     // kappa: the level of the bound for this cohort's unrelated pairs (from its mean missing
     // and het rates) plus 4.6 standard deviations and a little
     float kappa = -1.f;
@@ -520,8 +598,15 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
     // per tile (1.5-3 % of configs[1]) that a clean cohort need not pay; a cohort that is
     // clean on average but holds a few bad samples then carries its dense tiles to their
     // end before the quadrant lists take them over.
-    if (a.check0 == 2 || (a.check0 == 1 && kappa > 0.7f * a.kin_threshold))
-      chk0 = a.check_steps[0];
+    // k-steps from phase boundary `phase` on that cover `share` phases (around the end)
+    auto steps_of = [&](uint32_t share) {
+      const uint32_t hi = phase + share;
+      return hi <= kNumPhases ? phase_step(all_steps, hi) - k0
+                              : (all_steps - k0) + phase_step(all_steps, hi - kNumPhases);
+    };
+    if ((a.check0 == 2 || (a.check0 == 1 && kappa > 0.7f * a.kin_threshold)) &&
+        a.check_steps[0] != 0)
+      chk0 = steps_of(kCheckShares64[0]);
     const uint32_t sw1 = a.check1 & 0xFFu;
     if (sw1 >= 2) {
       entry1 = sw1 - 2;
@@ -538,13 +623,67 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
              (kCheckShares64[k] == 61 && (float)kCheckShares64[k] >= f64 + 0.5f)))
           entry1 = k;
     }
-    if (entry1 >= 1 && entry1 < kNumCheckShares) chk1 = a.check_steps[entry1];
+#pragma unroll
+    for (uint32_t k = 1; k < kNumCheckShares; ++k)
+      if (k == entry1) share1 = kCheckShares64[k];
+    if (share1 != 0 && a.check_steps[entry1] != 0) chk1 = steps_of(share1);
     if (chk0 >= num_steps) chk0 = 0;
     if (chk1 >= num_steps || chk1 <= chk0) chk1 = 0;
   }
   chk0 = __builtin_amdgcn_readfirstlane(chk0);
   chk1 = __builtin_amdgcn_readfirstlane(chk1);
-  entry1 = __builtin_amdgcn_readfirstlane(entry1);
+  share1 = __builtin_amdgcn_readfirstlane(share1);
+  phase = __builtin_amdgcn_readfirstlane(phase);
+  k0 = __builtin_amdgcn_readfirstlane(k0);
+  wrap = __builtin_amdgcn_readfirstlane(wrap);
+  start_abs = __builtin_amdgcn_readfirstlane(start_abs);
+  // u of plane sample idx over the `share` phases from this tile's first on (`total`: over
+  // all sites): cumulative counts in front of boundaries 1 .. 63, nothing in front of 0
+  auto prefix_u_of = [&](uint32_t share, size_t idx, float total) {
+    const uint32_t hi = phase + share;
+    const uint32_t xb = hi > kNumPhases ? hi - kNumPhases : hi;  // (uniform)
+    float u = hi > kNumPhases ? total : 0.f;
+    if (xb == kNumPhases)
+      u += total;
+    else if (xb != 0)
+      u += a.prefix_u[(size_t)(xb - 1) * s_stride + idx];
+    if (phase != 0) u -= a.prefix_u[(size_t)(phase - 1) * s_stride + idx];
+    return u;
+  };
+  // The k-step this tile has reached, for the tiles of the XCD that start next (one lane of
+  // one wavefront: the branch is scalar, the lane mask is set by hand -- a divergent branch
+  // here makes the compiler treat the segment loop as divergent)
+  unsigned long long *const pos_word =
+      reinterpret_cast<unsigned long long *>(a.filter_ctrl + kCtrlPos) +
+      (blockIdx.x & 7) * kPosSlots + ((blockIdx.x >> 3) & (kPosSlots - 1));
+  uint32_t *const ticks_word = a.filter_ctrl + kCtrlStepTicks + (blockIdx.x & 7);
+  // (the first request of the tile goes out about now)
+  const uint32_t t_start = a.rotate == 1 ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u;
+#define F_PUBLISH(STEPS)                                                       \
+  if (a.rotate == 1 && wave == 0) {                                            \
+    const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memrealtime();          \
+    const unsigned long long val_ =                                            \
+        ((unsigned long long)(start_abs + (STEPS)) << 32) | now_;              \
+    /* ticks per k-step x 16, once the tile has made enough of them to tell */ \
+    const uint32_t t16_ = (STEPS) >= 32 ? (now_ - t_start) * 16u / (STEPS) : 0u; \
+    const uint32_t zero_ = 0;                                                  \
+    unsigned long long save_;                                                  \
+    asm volatile("s_mov_b64 %0, exec\n\t"                                      \
+                 "s_mov_b64 exec, 1\n\t"                                       \
+                 "global_store_dwordx2 %1, %2, %3\n\t"                         \
+                 "s_mov_b64 exec, %0"                                          \
+                 : "=&s"(save_)                                                \
+                 : "v"(zero_), "v"(val_), "s"(pos_word)                        \
+                 : "memory");                                                  \
+    if (t16_ != 0)                                                             \
+      asm volatile("s_mov_b64 %0, exec\n\t"                                    \
+                   "s_mov_b64 exec, 1\n\t"                                     \
+                   "global_store_dword %1, %2, %3\n\t"                         \
+                   "s_mov_b64 exec, %0"                                        \
+                   : "=&s"(save_)                                              \
+                   : "v"(zero_), "v"(t16_), "s"(ticks_word)                    \
+                   : "memory");                                                \
+  }
 
   uint32_t seg_first = 0;  // k-steps of the piece behind us
   // the tile left at a check point (uniform): at the forecast, or at the rigorous check --
@@ -558,8 +697,13 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
     if (chk0 > seg_first) seg_end = chk0;
     seg_end = __builtin_amdgcn_readfirstlane(seg_end);
     seg_steps = seg_end - seg_first;
-    seg_src = g_wave + (uint64_t)seg_first * kstep_bytes;
-    asm volatile("" : "+s"(seg_src), "+s"(seg_steps));
+    // (the segment's first k-step of the bitset: behind the end of the sites it counts from
+    //  0 again; a segment that holds the end goes around it without a pause)
+    const uint32_t seg_k = seg_first >= wrap && wrap != 0 ? seg_first - wrap : k0 + seg_first;
+    seg_src = g_wave + (uint64_t)seg_k * kstep_bytes;
+    seg_wrap = __builtin_amdgcn_readfirstlane(
+        wrap > seg_first && wrap < seg_end ? wrap - seg_first : 0xFFFFFFFFu);
+    asm volatile("" : "+s"(seg_src), "+s"(seg_steps), "+s"(seg_wrap));
 
     // Stages 0 .. 3 of the segment requested, stage 0 landed.
 #pragma unroll
@@ -602,6 +746,7 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
     // become the check's or the epilogue's scratch.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     __syncthreads();
+    F_PUBLISH(seg_end)
     if (seg_end == num_steps) break;
 
     // --- the check behind k-step seg_end of the tile
@@ -611,7 +756,7 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
     float2 *const ck_cols = ck_rows + kT;
     uint32_t *const ck_words = reinterpret_cast<uint32_t *>(ck_cols + kT);  // one per wavefront
     {
-      const float *const pu = a.prefix_u + (size_t)(forecast ? 0u : entry1) * s_stride;
+      const uint32_t share = forecast ? kCheckShares64[0] : share1;  // (uniform)
       // (the forecast counts the pairs that WILL be candidates from an eighth of the sites:
       //  the bound of an unrelated pair scatters sqrt(8) times as widely there as at the
       //  end, 1 / sqrt(sites).  A quadrant goes dense from 2.3 % candidates on -- pairs two
@@ -625,8 +770,9 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
       const float t = 2.f - 4.f * thr_f;
       const size_t ir = (size_t)tr * kT + threadIdx.x;
       const size_t ic = (size_t)a.geo.col_base + (size_t)tc * kT + threadIdx.x;
-      ck_rows[threadIdx.x] = make_float2(pu[ir], scale * fmaf(t, a.sample_stats[ir].y, 8.f));
-      ck_cols[threadIdx.x] = make_float2(pu[ic], scale * fmaf(t, a.sample_stats[ic].y, 8.f));
+      const float2 sr = a.sample_stats[ir], sc = a.sample_stats[ic];
+      ck_rows[threadIdx.x] = make_float2(prefix_u_of(share, ir, sr.x), scale * fmaf(t, sr.y, 8.f));
+      ck_cols[threadIdx.x] = make_float2(prefix_u_of(share, ic, sc.x), scale * fmaf(t, sc.y, 8.f));
     }
     __syncthreads();
     const uint32_t emit_cap = a.check1 >> 8;  // (uniform; king_common.h check1)
@@ -687,8 +833,12 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
 #undef F_PINF
 #undef F_READ
 #undef F_ISSUE4
+#undef F_PUBLISH
   if (left && left_emit && threadIdx.x == 0)
     __hip_atomic_fetch_add(a.filter_totals + kTotalEarly, 1ull, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+  if (phase != 0 && threadIdx.x == 0)
+    __hip_atomic_fetch_add(a.filter_totals + kTotalRotated, 1ull, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
   if (left && !left_emit) {
     // Forecast: the tile leaves for the exact kernel -- its quadrants count as handed
@@ -808,9 +958,8 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
       // (the tile left at the rigorous check with a few live pairs: the same test on the
       //  sums and the per-sample counts of the sites so far -- every record is among the
       //  pairs it admits, king_filter.hip "Check points")
-      const float *const pu = a.prefix_u + (size_t)entry1 * s_stride;
-      r.x = pu[ir];
-      c.x = pu[ic];
+      r.x = prefix_u_of(share1, ir, r.x);
+      c.x = prefix_u_of(share1, ic, c.x);
     }
     r.y = fmaf(t, r.y, 8.f);
     c.y = fmaf(t, c.y, 8.f);
@@ -1006,8 +1155,9 @@ hipError_t launch_sample_stats(const uint64_t *d_bit_sets, uint32_t words_per_sa
   uint32_t *steps = const_cast<uint32_t *>(plane_check_steps(d_planes, geo));
   CheckWords cw;
   const uint32_t all_steps = geo.k_words / 8;  // k-steps of 256 sites
+  if (all_steps > kStatsMaxSteps) return hipErrorInvalidValue;
   for (uint32_t k = 0; k < kNumCheckShares; ++k)
-    cw.w[k] = 4 * check_step_of(all_steps, k, g_check_min_steps.load());
+    cw.w[k] = check_step_of(all_steps, k, g_check_min_steps.load());
   sample_stats_kernel<<<dim3((s_end - s_begin + 3) / 4), dim3(256), 0, stream>>>(
       d_bit_sets, words_per_sample, geo, stats, prefix, sums, steps, cw, s_begin, s_end);
   return hipGetLastError();
@@ -1048,6 +1198,7 @@ hipError_t launch_filter(const TiledArgs &args, uint64_t num_tiles, hipStream_t 
     // would have to give up make up most of the launch before anybody has finished
     a.check0 = !checks ? 0u : args.check0 == 2 ? 2u : (args.check0 == 1 && n < 16ull * wgs) ? 1u : 0u;
     a.check1 = checks ? args.check1 : 0u;
+    a.rotate = checks ? args.rotate : 0u;
     // Short launches: the tiles beyond whole rounds of one per CU would leave most
     // CUs idle for a whole tile time; each of them is cut into `parts` pieces of k
     // instead (same launch, behind the whole tiles).

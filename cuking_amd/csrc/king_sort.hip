@@ -64,7 +64,7 @@ __global__ void apply_order_kernel(PlaneGeometry geo, uint32_t begin, uint32_t e
     perm[p] = kNoSample;
     stats[p] = make_float2(0.f, 0.f);
 #pragma unroll
-    for (uint32_t c = 0; c < kNumCheckShares; ++c) prefix[(size_t)c * geo.s_stride + p] = 0.f;
+    for (uint32_t c = 0; c < kNumCum; ++c) prefix[(size_t)c * geo.s_stride + p] = 0.f;
     return;
   }
   const uint32_t src = order[p - begin];  // plane sample in stored order
@@ -72,8 +72,8 @@ __global__ void apply_order_kernel(PlaneGeometry geo, uint32_t begin, uint32_t e
   // the rows (cuking.cu:171-175)
   perm[p] = (geo.diag || src < geo.rows_padded) ? src : geo.num_rows + (src - geo.col_base);
   stats[p] = tmp_stats[src];
-#pragma unroll
-  for (uint32_t c = 0; c < kNumCheckShares; ++c)
+#pragma unroll 7
+  for (uint32_t c = 0; c < kNumCum; ++c)
     prefix[(size_t)c * geo.s_stride + p] = tmp_prefix[(size_t)c * geo.s_stride + src];
 }
 

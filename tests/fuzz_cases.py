@@ -114,6 +114,8 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
         chk1 = int(rng.choice([1, 0, 3, 5, 7, 9]))
         srt, lazy = int(rng.integers(0, 3)), int(rng.integers(0, 2))   # sorted layout, lazy codes
         emit = int(rng.choice([64, 64, 0, 1, 255]))    # live pairs a tile hands over at the check
+        # rotated tiles: as shipped (joins the XCD's position) / off / a phase per tile / one phase
+        rot = int(rng.choice([1, 0, 2, 2, 3 + int(rng.integers(0, 64))]))
         if case < first_case:
             continue
         tag = dict(fuzzer="run_general", seed=seed, case=case, n=n, m=m, split_factor=k,
@@ -121,7 +123,8 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
                    xcd_swizzle=swizzle, band_rows=band, split_wgs=wgs, reuse_prepared=reuse,
                    filter_quadrant_cap=qcap, filter_cand_cap=ccap, filter_split_min_steps=smin,
                    filter_check0=chk0, filter_check1=chk1, filter_check_min_steps=4,
-                   filter_sort=srt, filter_lazy_codes=lazy, filter_check_emit=emit)
+                   filter_sort=srt, filter_lazy_codes=lazy, filter_check_emit=emit,
+                   filter_rotate=rot, filter_rotate_min_steps=4)
         osm = pyoracle.submatrix(n, k, shard)
         bits = pyoracle.bitset_from_genotypes(geno, osm)
         exp, _, _ = pyoracle.compute(osm, bits, thr, threads=8)
@@ -138,6 +141,8 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
         ctx.set_option("filter_check0", chk0)
         ctx.set_option("filter_check1", chk1)
         ctx.set_option("filter_check_emit", emit)
+        ctx.set_option("filter_rotate", rot)
+        ctx.set_option("filter_rotate_min_steps", 4)
         ctx.set_option("filter_check_min_steps", 4)
         ctx.set_option("filter_sort", srt)
         ctx.set_option("filter_lazy_codes", lazy)
@@ -176,6 +181,8 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
     ctx.set_option("filter_check0", 1)
     ctx.set_option("filter_check1", 1)
     ctx.set_option("filter_check_emit", 64)
+    ctx.set_option("filter_rotate", 1)
+    ctx.set_option("filter_rotate_min_steps", 128)
     ctx.set_option("filter_check_min_steps", 64)
     ctx.set_option("filter_sort", 1)
     ctx.set_option("filter_lazy_codes", 1)

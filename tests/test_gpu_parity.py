@@ -1262,9 +1262,10 @@ def test_filter_check_points_inside_the_k_loop(ctx, oracle, missing):
     sub = np.ascontiguousarray(bits[idx])
     d_sub = ctx.upload_bitset(sub)
     defaults = {"filter_check0": 1, "filter_check1": 1, "filter_check_emit": 64,
-                "filter_split_min_steps": 8,
+                "filter_rotate": 1, "filter_split_min_steps": 8,
                 "max_launch_blocks": 0, "filter_quadrant_cap": 384, "split_wgs": 256}
     ctx.set_option("filter_check_min_steps", 4)
+    ctx.set_option("filter_rotate_min_steps", 4)
     try:
         for thr in (0.03, 0.0884, 0.2):
             exp, _, _ = oracle.compute(oracle.submatrix(n), bits, thr, threads=16)
@@ -1282,6 +1283,16 @@ def test_filter_check_points_inside_the_k_loop(ctx, oracle, missing):
                       for k in range(1, 8)]
             cases += [{"filter_check0": 0, "filter_check_emit": e, "split_wgs": 0}
                       for e in (0, 1, 100)]
+            # rotated tiles: every tile starts at a phase boundary of its own (2), all at one
+            # (3 + phase), with the forecast, a forced entry, the remainder pieces
+            cases += [{"filter_rotate": 2, "split_wgs": 0}, {"filter_rotate": 2},
+                      {"filter_rotate": 2, "filter_check0": 2, "split_wgs": 0},
+                      {"filter_rotate": 2, "filter_check0": 2, "filter_check1": 0, "split_wgs": 0},
+                      {"filter_rotate": 2, "filter_check0": 2, "filter_quadrant_cap": 0, "split_wgs": 0}]
+            cases += [{"filter_rotate": 3 + ph, "filter_check0": c0, "filter_check1": 2 + k,
+                       "split_wgs": 0}
+                      for ph, c0, k in ((1, 0, 3), (9, 2, 1), (13, 0, 7), (31, 2, 4), (40, 0, 2),
+                                        (57, 2, 5), (63, 0, 3), (63, 2, 7))]
             for opts in cases:
                 for k, v in {**defaults, **opts}.items():
                     ctx.set_option(k, v)
@@ -1312,9 +1323,60 @@ def test_filter_check_points_inside_the_k_loop(ctx, oracle, missing):
                 assert got.tobytes() == e2.tobytes(), (thr, opts, "off-diagonal block")
     finally:
         ctx.set_option("filter_check_min_steps", 64)
+        ctx.set_option("filter_rotate_min_steps", 128)
         for k, v in defaults.items():
             ctx.set_option(k, v)
         ctx.set_option("counts_mode", -1)
+
+
+def test_filter_rotated_tiles_join_the_position_of_their_xcd(ctx, oracle):
+    """Rotated tiles (king_filter.hip): a tile starts its k loop at the phase boundary the
+    tiles of its XCD have reached, runs to the end of the sites, wraps around and ends where
+    it started -- so that the tiles an XCD holds at a time read the same k-steps at the
+    same time and share them through its L2.  300 tiles on 256 CUs at a threshold where
+    the tiles leave at the check point: the tiles of the second round start where the first
+    left (another phase than the first), the oracle's records either way, whole block and
+    off-diagonal block."""
+    select(ctx, "tiled", 7, counts_mode=0)
+    rng = np.random.default_rng(97)
+    n, m = 6000, 6200                          # 24 x 24 tiles of 256; 25 k-steps of 256 sites
+    geno = random_genotypes(rng, n, m, missing=0.01)
+    geno[n - 1], geno[3000], geno[5900], geno[300] = geno[7], geno[130], geno[5899], geno[299]
+    bits = oracle.bitset_from_genotypes(geno)
+    d_bits = ctx.upload_bitset(bits)
+    sm = cuking_amd.Submatrix(n)
+    off = cuking_amd.Submatrix(n, 2, 1)
+    idx = list(range(off.i_begin, off.i_end)) + list(range(off.j_begin, off.j_end))
+    sub = np.ascontiguousarray(bits[idx])
+    d_sub = ctx.upload_bitset(sub)
+    thr = 0.2
+    exp, _, _ = oracle.compute(oracle.submatrix(n), bits, thr, threads=16)
+    e2, _, _ = oracle.compute(oracle.submatrix(n, 2, 1), sub, thr, threads=16)
+    assert len(exp) >= 4
+    ctx.set_option("filter_check_min_steps", 4)
+    ctx.set_option("filter_rotate_min_steps", 4)
+    ctx.set_option("split_wgs", 0)             # whole tiles only (remainder pieces never rotate)
+    try:
+        for rotate in (1, 0, 1):
+            ctx.set_option("filter_rotate", rotate)
+            r0 = ctx.get_option("filter_rotated_tiles")
+            x0 = ctx.get_option("filter_early_exits")
+            got = ctx.run(sm, bits.shape[1], d_bits, thr, max_results=1 << 20)
+            assert got.tobytes() == exp.tobytes(), rotate
+            rotated = ctx.get_option("filter_rotated_tiles") - r0
+            exits = ctx.get_option("filter_early_exits") - x0
+            # 300 tiles, 24 on the diagonal: the others leave at the check
+            assert exits >= 250, (rotate, exits)
+            if rotate:
+                assert 1 <= rotated <= 300 - 256 + 8, (rotate, rotated)
+            else:
+                assert rotated == 0
+            got = ctx.run(off, bits.shape[1], d_sub, thr, max_results=1 << 20)
+            assert got.tobytes() == e2.tobytes(), (rotate, "off-diagonal block")
+    finally:
+        for k, v in (("filter_check_min_steps", 64), ("filter_rotate_min_steps", 128),
+                     ("filter_rotate", 1), ("split_wgs", 256), ("counts_mode", -1)):
+            ctx.set_option(k, v)
 
 
 def test_filter_sorted_layout_and_lazy_codes(ctx, oracle):
