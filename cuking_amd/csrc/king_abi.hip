@@ -132,6 +132,7 @@ struct cuking_ctx {
   // bitsets of fewer k-steps (of 256 sites) than the minimum are not rotated.
   int filter_rotate = 1;
   uint32_t filter_rotate_min_steps = 128;
+  uint32_t filter_rotate_min_tiles = 2048;  // 8 rounds of one tile per CU
   // The kernel layout's samples sorted by their share of missing calls (king_sort.hip);
   // the four-product kernel's codes converted only when the filter needs them
   // (0: with every conversion).
@@ -363,7 +364,7 @@ cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const Plan
   a->cohort_sums = nullptr;
   a->check_steps = nullptr;
   a->check0 = a->check1 = 0;
-  a->rotate = a->rotate_min_steps = 0;
+  a->rotate = a->rotate_min_steps = a->rotate_min_tiles = 0;
   if (ctx->variant != kMfmaFilterVariant) return CUKING_OK;
   const FilterScratchLayout want = filter_scratch_layout(tiles);
   cuking_ctx::FilterScratch *entry = nullptr;
@@ -427,6 +428,7 @@ cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const Plan
   a->check1 = (uint32_t)ctx->filter_check1 | ((uint32_t)ctx->filter_check_emit << 8);
   a->rotate = (uint32_t)ctx->filter_rotate;
   a->rotate_min_steps = ctx->filter_rotate_min_steps;
+  a->rotate_min_tiles = ctx->filter_rotate_min_tiles;
   a->check_steps = plane_check_steps(ctx->planes, geo);
   return CUKING_OK;
 }
@@ -977,6 +979,12 @@ cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
     ctx->filter_rotate = (int)value;
     return CUKING_OK;
   }
+  if (strcmp(key, "filter_rotate_min_tiles") == 0) {
+    if (value < 0 || value > (1 << 30))
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "filter_rotate_min_tiles outside [0, 2^30]");
+    ctx->filter_rotate_min_tiles = (uint32_t)value;
+    return CUKING_OK;
+  }
   if (strcmp(key, "filter_rotate_min_steps") == 0) {
     if (value < 1 || value > (1 << 20))
       return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "filter_rotate_min_steps outside [1, 2^20]");
@@ -1236,6 +1244,7 @@ cuking_status cuking_ctx_get_option(const cuking_ctx *ctx, const char *key,
   else if (strcmp(key, "filter_check_emit") == 0) *value = ctx->filter_check_emit;
   else if (strcmp(key, "filter_rotate") == 0) *value = ctx->filter_rotate;
   else if (strcmp(key, "filter_rotate_min_steps") == 0) *value = ctx->filter_rotate_min_steps;
+  else if (strcmp(key, "filter_rotate_min_tiles") == 0) *value = ctx->filter_rotate_min_tiles;
   else if (strcmp(key, "filter_candidates") == 0 || strcmp(key, "filter_dense_quadrants") == 0 ||
            strcmp(key, "filter_early_exits") == 0 || strcmp(key, "filter_rotated_tiles") == 0) {
     // Diagnostics (they WAIT for the device): pairs the bound let through, quadrants

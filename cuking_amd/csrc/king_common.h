@@ -217,7 +217,7 @@ struct TiledArgs {
   // check_steps[k] (device memory, written by the kernel that computed the counts): k-steps
   // behind share k of kCheckShares64 from the first site on (0 = bitset too short for
   // checks); prefix_u[(x - 1) * s_stride + s]: u of plane sample s over the k-steps in front
-  // of phase boundary x = 1 .. 63 (king_common.h phase_step).
+  // of phase boundary x = 1 .. kNumCum (king_common.h phase_step).
   // Entry 0 is the forecast's (used when check0 != 0: short launches), entries 1 .. the
   // rigorous check's: every workgroup picks the same one from the threshold and the
   // cohort's mean missing and het rates (cohort_sums: samples, missing calls, het calls).
@@ -232,8 +232,10 @@ struct TiledArgs {
   // with check points starts at the phase boundary the other tiles of its XCD are at
   // (filter_ctrl + kCtrlPos: one position word per XCD) and wraps around; 2 test hook: a
   // phase drawn from the tile's index; 3 + j test hook: phase j.  rotate_min_steps: bitsets
-  // of fewer k-steps are not rotated.
+  // of fewer k-steps are not rotated; nor are launches of fewer than rotate_min_tiles tiles
+  // (the tiles of a few rounds have not drifted apart yet).
   uint32_t rotate, rotate_min_steps;
+  uint32_t rotate_min_tiles;  // (host side: launches of fewer tiles are not rotated)
   // one flag per tile of the launch chunk, directly behind the chunk's control words
   // (filter_ctrl + kCtrlChunkBytes: one memset clears both in front of a chunk)
   uint8_t *tile_done;
@@ -270,13 +272,14 @@ struct TiledArgs {
 constexpr uint32_t kCheckEmitCap = 64;
 constexpr uint32_t kNumCheckShares = 8;
 constexpr uint32_t kCheckShares64[kNumCheckShares] = {8, 50, 53, 56, 58, 60, 61, 62};
-// The k-steps of a bitset in 64 PHASES: phase x is k-steps [phase_step(x), phase_step(x + 1)).
+// The k-steps of a bitset in kNumPhases PHASES: phase x is k-steps [phase_step(x), phase_step(x + 1)).
 // A tile may start its k loop at any phase boundary and wrap around (king_filter.hip,
 // "Rotated tiles": the tiles an XCD holds at a time read the same k-steps at the same time,
 // whenever each of them started), so the per-sample prefix counts are kept CUMULATIVE at
 // every phase boundary: u over phases [a, b) is the difference of two of them.
-constexpr uint32_t kNumPhases = 64;
-constexpr uint32_t kNumCum = kNumPhases - 1;  // boundaries 1 .. 63 (0 is zero, 64 the total)
+constexpr uint32_t kNumPhases = 128;  // (a multiple of 64: the checks' shares are 64ths)
+constexpr uint32_t kPhasesPerShare = kNumPhases / 64;
+constexpr uint32_t kNumCum = kNumPhases - 1;  // inner boundaries (0 is zero, the last the total)
 __host__ __device__ inline uint32_t phase_step(uint32_t all_steps, uint32_t x) {
   return (uint32_t)((uint64_t)all_steps * x / kNumPhases);
 }
@@ -285,7 +288,7 @@ __host__ __device__ inline uint32_t phase_step(uint32_t all_steps, uint32_t x) {
 __host__ __device__ inline uint32_t check_step_of(uint32_t all_steps, uint32_t k,
                                                   uint32_t min_steps = 64) {
   if (all_steps < min_steps) return 0;
-  return phase_step(all_steps, kCheckShares64[k]);
+  return phase_step(all_steps, kCheckShares64[k] * kPhasesPerShare);
 }
 // Remainder splitting: at most this many pieces per launch (one per CU), a slab of
 // 256 x 256 float sums and a ticket word each.

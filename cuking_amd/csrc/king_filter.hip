@@ -93,7 +93,7 @@ __device__ __forceinline__ uint32_t source_sample(const PlaneGeometry &geo, uint
 // sites).  Padding sites of the last word are missing (cuking.cu:513-523) and
 // count as such; padding samples get (0, 0).  Beside them the same |Y| - |M|
 // CUMULATIVE at every phase boundary of the k-steps (king_common.h phase_step:
-// cum[x - 1][sample] = over the first 256 phase_step(x) sites, x = 1 .. 63) -- what a
+// cum[x - 1][sample] = over the first 256 phase_step(x) sites, x = 1 .. 127) -- what a
 // check point of a tile that started at any phase needs --, and the cohort's sums
 // (samples, missing calls, het calls) the kernel picks a check from.
 struct CheckWords {
@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void sample_stats_kernel(
     const uint32_t x = (kNumPhases * (st + 1) - 1) / all_steps;
     phase_of[st] = (uint8_t)(x < kNumPhases ? x : kNumPhases - 1);
   }
-  phase_sum[wave][lane] = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kNumPhases / 64; ++k) phase_sum[wave][lane + 64 * k] = 0;
   __syncthreads();
   const uint32_t ps = s_begin + blockIdx.x * 4 + wave;
   if (ps >= s_end) return;  // whole wavefront
@@ -157,14 +158,18 @@ __global__ __launch_bounds__(256) void sample_stats_kernel(
     }
   }
   // (the wavefront's own LDS adds are done: same wavefront, in order) inclusive scan over
-  // the phases: lane x holds the count in front of boundary x + 1
-  int32_t run = phase_sum[wave][lane];
+  // the phases -- lane l holds phases 2 l and 2 l + 1 --: the count in front of boundary x + 1
+  // is the scan's value at phase x
+  static_assert(kNumPhases == 128, "two phases per lane");
+  const int32_t p0 = phase_sum[wave][2 * lane], p1 = phase_sum[wave][2 * lane + 1];
+  int32_t run = p0 + p1;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     const int32_t up = __shfl_up(run, off);
     if ((int)lane >= off) run += up;
   }
-  if (lane < kNumCum) cum[(size_t)lane * geo.s_stride + ps] = (float)run;
+  cum[(size_t)(2 * lane) * geo.s_stride + ps] = (float)(run - p1);
+  if (2 * lane + 1 < kNumCum) cum[(size_t)(2 * lane + 1) * geo.s_stride + ps] = (float)run;
   if (lane == 0) {
     stats[ps] = make_float2((float)(yc - mc), (float)hc);
     // (the cohort's sums feed a choice, not a result: a sample of the samples will do --
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   // fabric per pass of configs[2]; one launch per round: 0.80 and 170 GB, and the chip
   // holds 1.96-1.99 GHz instead of 1.86: tools/l2_probe.sh).  The order of the sites
   // inside a sum does not matter, so a tile STARTS where the tiles of its XCD are: at the
-  // phase boundary (king_common.h phase_step: 64 phases) nearest to the k-step the most
+  // phase boundary (king_common.h phase_step: 128 phases) nearest to the k-step the most
   // advanced of them has published, runs to the end of the sites, wraps around (a segment
   // boundary like a check point's) and ends where it started.  A check point sits behind a
   // share of the k-steps as before; the per-sample counts over "phases [p, p + e)" are
@@ -600,7 +605,7 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
     // end before the quadrant lists take them over.
     // k-steps from phase boundary `phase` on that cover `share` phases (around the end)
     auto steps_of = [&](uint32_t share) {
-      const uint32_t hi = phase + share;
+      const uint32_t hi = phase + share * kPhasesPerShare;
       return hi <= kNumPhases ? phase_step(all_steps, hi) - k0
                               : (all_steps - k0) + phase_step(all_steps, hi - kNumPhases);
     };
@@ -611,21 +616,22 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
     if (sw1 >= 2) {
       entry1 = sw1 - 2;
     } else if (sw1 == 1 && kappa >= 0.f) {
+      // The share behind which no unrelated pair of this cohort is still under the bound, in
+      // 64ths, rounded up -- any of them: the counts are there at every phase boundary.  (A
+      // check costs a tile that leaves ~1.5 % -- the drain, the sweep -- and one that stays
+      // ~3 % -- the refill as well; a tile that still holds a few live pairs leaves all the
+      // same, handing them over, so the share needs no margin: up to 62/64.  The menu of
+      // king_common.h is what "filter_check1" = 2 + k forces.)
       const float f64 = 64.f * (1.f - 2.f * a.kin_threshold) / (1.f - 2.f * kappa);
-      // (a check costs a tile that leaves ~1.5 % -- the drain, the sweep -- and one that
-      //  stays ~3 % -- the refill as well: entries up to 60/64 are taken when the forecast
-      //  share reaches them, 61/64 only with half a step of margin to spare -- 200k sites
-      //  at threshold 0.05 --, the later ones are for tests)
-#pragma unroll
-      for (uint32_t k = kNumCheckShares - 1; k >= 1; --k)
-        if ((float)kCheckShares64[k] >= f64 &&
-            (kCheckShares64[k] <= 60 ||
-             (kCheckShares64[k] == 61 && (float)kCheckShares64[k] >= f64 + 0.5f)))
-          entry1 = k;
+      if (f64 <= 62.f) {
+        share1 = (uint32_t)ceilf(f64);
+        if (share1 < 32) share1 = 32;
+        entry1 = 1;  // (any entry of the menu: whether the bitset is long enough for checks)
+      }
     }
 #pragma unroll
     for (uint32_t k = 1; k < kNumCheckShares; ++k)
-      if (k == entry1) share1 = kCheckShares64[k];
+      if (sw1 >= 2 && k == entry1) share1 = kCheckShares64[k];
     if (share1 != 0 && a.check_steps[entry1] != 0) chk1 = steps_of(share1);
     if (chk0 >= num_steps) chk0 = 0;
     if (chk1 >= num_steps || chk1 <= chk0) chk1 = 0;
@@ -638,9 +644,9 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   wrap = __builtin_amdgcn_readfirstlane(wrap);
   start_abs = __builtin_amdgcn_readfirstlane(start_abs);
   // u of plane sample idx over the `share` phases from this tile's first on (`total`: over
-  // all sites): cumulative counts in front of boundaries 1 .. 63, nothing in front of 0
+  // all sites): cumulative counts in front of the inner boundaries, nothing in front of 0
   auto prefix_u_of = [&](uint32_t share, size_t idx, float total) {
-    const uint32_t hi = phase + share;
+    const uint32_t hi = phase + share * kPhasesPerShare;
     const uint32_t xb = hi > kNumPhases ? hi - kNumPhases : hi;  // (uniform)
     float u = hi > kNumPhases ? total : 0.f;
     if (xb == kNumPhases)
@@ -1198,7 +1204,9 @@ hipError_t launch_filter(const TiledArgs &args, uint64_t num_tiles, hipStream_t 
     // would have to give up make up most of the launch before anybody has finished
     a.check0 = !checks ? 0u : args.check0 == 2 ? 2u : (args.check0 == 1 && n < 16ull * wgs) ? 1u : 0u;
     a.check1 = checks ? args.check1 : 0u;
-    a.rotate = checks ? args.rotate : 0u;
+    // (rotated tiles: for launches of many rounds -- the tiles of a few rounds have not
+    //  drifted apart yet, configs[1] has an L2 hit rate of 0.76 without)
+    a.rotate = checks && (n >= args.rotate_min_tiles || args.rotate >= 2) ? args.rotate : 0u;
     // Short launches: the tiles beyond whole rounds of one per CU would leave most
     // CUs idle for a whole tile time; each of them is cut into `parts` pieces of k
     // instead (same launch, behind the whole tiles).

@@ -143,6 +143,7 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
         ctx.set_option("filter_check_emit", emit)
         ctx.set_option("filter_rotate", rot)
         ctx.set_option("filter_rotate_min_steps", 4)
+        ctx.set_option("filter_rotate_min_tiles", 0)
         ctx.set_option("filter_check_min_steps", 4)
         ctx.set_option("filter_sort", srt)
         ctx.set_option("filter_lazy_codes", lazy)
@@ -183,6 +184,7 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
     ctx.set_option("filter_check_emit", 64)
     ctx.set_option("filter_rotate", 1)
     ctx.set_option("filter_rotate_min_steps", 128)
+    ctx.set_option("filter_rotate_min_tiles", 2048)
     ctx.set_option("filter_check_min_steps", 64)
     ctx.set_option("filter_sort", 1)
     ctx.set_option("filter_lazy_codes", 1)

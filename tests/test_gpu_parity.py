@@ -1355,6 +1355,7 @@ def test_filter_rotated_tiles_join_the_position_of_their_xcd(ctx, oracle):
     assert len(exp) >= 4
     ctx.set_option("filter_check_min_steps", 4)
     ctx.set_option("filter_rotate_min_steps", 4)
+    ctx.set_option("filter_rotate_min_tiles", 0)
     ctx.set_option("split_wgs", 0)             # whole tiles only (remainder pieces never rotate)
     try:
         for rotate in (1, 0, 1):
@@ -1375,7 +1376,8 @@ def test_filter_rotated_tiles_join_the_position_of_their_xcd(ctx, oracle):
             assert got.tobytes() == e2.tobytes(), (rotate, "off-diagonal block")
     finally:
         for k, v in (("filter_check_min_steps", 64), ("filter_rotate_min_steps", 128),
-                     ("filter_rotate", 1), ("split_wgs", 256), ("counts_mode", -1)):
+                     ("filter_rotate_min_tiles", 2048), ("filter_rotate", 1), ("split_wgs", 256),
+                     ("counts_mode", -1)):
             ctx.set_option(k, v)
 
 
