@@ -139,15 +139,18 @@ __global__ __launch_bounds__(256) void sample_stats_kernel(
 #pragma unroll
       for (uint32_t k = 0; k < kAhead; ++k) {
         const uint32_t w = w0 + 64 * k + lane;
-        if (w < n) {  // (beyond the plane: contributes nothing)
-          const int32_t y = __popcll(~h[k]);    // homozygous and defined (missing has the het bit set)
-          const int32_t m = __popcll(h[k] & v[k]);  // missing
-          yc += y;
-          mc += m;
-          hc += __popcll(h[k] & ~v[k]);  // het
-          // (a k-step is 4 words of 64 sites; ~24 lanes share a phase: LDS adds)
-          atomicAdd(&phase_sum[wave][phase_of[w >> 2]], y - m);
-        }
+        const bool in = w < n;  // (beyond the plane: contributes nothing)
+        const int32_t y = in ? __popcll(~h[k]) : 0;  // homozygous and defined (missing has the het bit set)
+        const int32_t m = __popcll(h[k] & v[k]);     // missing
+        yc += y;
+        mc += m;
+        hc += __popcll(h[k] & ~v[k]);  // het
+        // (a k-step is 4 words of 64 sites = 4 neighbouring lanes: their sum first, then ONE
+        //  LDS add per k-step -- a dozen lanes share a phase)
+        int32_t d = y - m;
+        d += __shfl_xor(d, 1);
+        d += __shfl_xor(d, 2);
+        if ((lane & 3) == 0 && in) atomicAdd(&phase_sum[wave][phase_of[w >> 2]], d);
       }
     }
 #pragma unroll
