@@ -348,12 +348,13 @@ def roofline_block(args, ctx, *, launch_pairs, sites, wps, thr, king_ms, prepare
 
 
 def filter_counters(ctx):
-    """(candidates, dense quadrants) so far, or None when the context's variant is not
+    """(candidates, dense quadrants, tiles that left early, tiles that started at another
+    phase) so far, or None when the context's variant is not
     the filter variant (diagnostic options of the library: they wait for the device)."""
     if ctx.get_option("variant") != 7:
         return None
     return (ctx.get_option("filter_candidates"), ctx.get_option("filter_dense_quadrants"),
-            ctx.get_option("filter_early_exits"))
+            ctx.get_option("filter_early_exits"), ctx.get_option("filter_rotated_tiles"))
 
 
 def records_of(results, count):
@@ -480,13 +481,19 @@ def single_gpu_workload(args, ctx, n, m, thr, steps, warmup, local_rank, clock_p
                          "dense_quadrants_per_pass": (filt1[1] - filt0[1]) / steps,
                          "tiles_left_at_the_check_point_per_pass": (filt1[2] - filt0[2]) / steps,
                          "tiles_per_pass": ctx.num_tiles(sm),
+                         "tiles_started_at_another_phase_per_pass": (filt1[3] - filt0[3]) / steps,
+                         "k_step_us_measured_by_the_tiles": ctx.get_option("filter_step_ticks16") / 1600.0,
                          "records_per_pass": len(recs),
                          "note": "filter variant: pairs its bound let through to the exact "
                                  "recount, 128 x 128 quadrants handed to the four-product "
                                  "kernel instead, 256 x 256 tiles that left at the rigorous "
                                  "check point inside the k loop (no pair of theirs could still "
-                                 "become a candidate: king_filter.hip), and the records of a "
-                                 "pass"}))
+                                 "become a candidate: king_filter.hip, or hand a few live "
+                                 "pairs to the candidate list and leave), tiles that started "
+                                 "their k loop where the tiles of their XCD were (rotated "
+                                 "tiles) with the time per k-step of 256 sites they measured "
+                                 "(100 MHz counter; 0 = launch too short to rotate), and the "
+                                 "records of a pass"}))
 
 
 def filter_worst_case(args, ctx, bits, n, m, thr, local_rank):

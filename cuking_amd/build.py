@@ -114,11 +114,12 @@ def check_filter_loop(asm_path: Path, verbose: bool = False):
     -DCUKING_FILTER_FINE=1) and must hold no scratch access and no other vmcnt wait."""
     import re
     text = Path(asm_path).read_text()
-    m = re.search(r"\n_ZN6cuking12_GLOBAL__N_118king_filter_kernelE\w+:(.*?)\.Lfunc_end", text, re.S)
-    if not m:
-        return [f"no king_filter_kernel in {asm_path}"]
+    bodies = [m.group(1) for m in re.finditer(
+        r"\n_ZN6cuking12_GLOBAL__N_1\d+king_filter(?:_persistent)?_kernelE\w+:(.*?)\.Lfunc_end", text, re.S)]
+    if len(bodies) < 2:
+        return [f"king_filter_kernel / king_filter_persistent_kernel not both in {asm_path}"]
     problems, seen = [], 0
-    for block in re.split(r"\n(?=\.LBB\d+_\d+:)", m.group(1)):
+    for block in (b for body in bodies for b in re.split(r"\n(?=\.LBB\d+_\d+:)", body)):
         lines = block.split("\n")
         head = lines[0].split(":")[0]
         end = next((i for i, l in enumerate(lines)
@@ -138,8 +139,8 @@ def check_filter_loop(asm_path: Path, verbose: bool = False):
                   f"vmcnt waits {waits}")
         if scratch or foreign:
             problems.append(f"king_filter_kernel, loop {head}: scratch {scratch[:2]}, waits {foreign}")
-    if seen == 0:
-        problems.append("king_filter_kernel: no LDS-DMA loop found (listing format changed?)")
+    if seen < 2:
+        problems.append("king_filter kernels: an LDS-DMA loop is missing (listing format changed?)")
     return problems
 
 

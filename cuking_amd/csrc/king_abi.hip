@@ -133,6 +133,11 @@ struct cuking_ctx {
   int filter_rotate = 1;
   uint32_t filter_rotate_min_steps = 128;
   uint32_t filter_rotate_min_tiles = 2048;  // 8 rounds of one tile per CU
+  // one resident workgroup per CU takes tile after tile (king_filter.hip): measured 1.2 % behind
+  // one workgroup per tile at configs[2] -- the chip is power-bound, a CU that waits for the
+  // dispatcher lends its share to the others -- so off unless asked for
+  bool filter_persistent = false;
+  uint32_t filter_persistent_min_tiles = 2048;
   // The kernel layout's samples sorted by their share of missing calls (king_sort.hip);
   // the four-product kernel's codes converted only when the filter needs them
   // (0: with every conversion).
@@ -365,6 +370,7 @@ cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const Plan
   a->check_steps = nullptr;
   a->check0 = a->check1 = 0;
   a->rotate = a->rotate_min_steps = a->rotate_min_tiles = 0;
+  a->persist_wgs = a->persist_min_tiles = 0;
   if (ctx->variant != kMfmaFilterVariant) return CUKING_OK;
   const FilterScratchLayout want = filter_scratch_layout(tiles);
   cuking_ctx::FilterScratch *entry = nullptr;
@@ -429,6 +435,8 @@ cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const Plan
   a->rotate = (uint32_t)ctx->filter_rotate;
   a->rotate_min_steps = ctx->filter_rotate_min_steps;
   a->rotate_min_tiles = ctx->filter_rotate_min_tiles;
+  a->persist_wgs = ctx->filter_persistent ? 1u : 0u;
+  a->persist_min_tiles = ctx->filter_persistent_min_tiles;
   a->check_steps = plane_check_steps(ctx->planes, geo);
   return CUKING_OK;
 }
@@ -979,6 +987,16 @@ cuking_status cuking_ctx_set_option(cuking_ctx *ctx, const char *key,
     ctx->filter_rotate = (int)value;
     return CUKING_OK;
   }
+  if (strcmp(key, "filter_persistent_min_tiles") == 0) {
+    if (value < 0 || value > (1 << 30))
+      return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "filter_persistent_min_tiles outside [0, 2^30]");
+    ctx->filter_persistent_min_tiles = (uint32_t)value;
+    return CUKING_OK;
+  }
+  if (strcmp(key, "filter_persistent") == 0) {
+    ctx->filter_persistent = value != 0;
+    return CUKING_OK;
+  }
   if (strcmp(key, "filter_rotate_min_tiles") == 0) {
     if (value < 0 || value > (1 << 30))
       return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "filter_rotate_min_tiles outside [0, 2^30]");
@@ -1245,6 +1263,8 @@ cuking_status cuking_ctx_get_option(const cuking_ctx *ctx, const char *key,
   else if (strcmp(key, "filter_rotate") == 0) *value = ctx->filter_rotate;
   else if (strcmp(key, "filter_rotate_min_steps") == 0) *value = ctx->filter_rotate_min_steps;
   else if (strcmp(key, "filter_rotate_min_tiles") == 0) *value = ctx->filter_rotate_min_tiles;
+  else if (strcmp(key, "filter_persistent") == 0) *value = ctx->filter_persistent ? 1 : 0;
+  else if (strcmp(key, "filter_persistent_min_tiles") == 0) *value = ctx->filter_persistent_min_tiles;
   else if (strcmp(key, "filter_candidates") == 0 || strcmp(key, "filter_dense_quadrants") == 0 ||
            strcmp(key, "filter_early_exits") == 0 || strcmp(key, "filter_rotated_tiles") == 0) {
     // Diagnostics (they WAIT for the device): pairs the bound let through, quadrants
@@ -1265,6 +1285,43 @@ cuking_status cuking_ctx_get_option(const cuking_ctx *ctx, const char *key,
       total += v;
     }
     *value = (int64_t)(total + ctx->filter_totals_retired[word]);
+  }
+  else if (strncmp(key, "filter_total_", 13) == 0) {
+    // Diagnostic (WAITS for the device): word N < 32 of the filter's running totals, summed
+    // over the context's streams -- the words behind the named ones are the timing build's
+    // (-DCUKING_FILTER_TIMING=1, king_filter.hip).
+    const int word = atoi(key + 13);
+    if (word < 0 || word >= 32) return cuking_fail(CUKING_ERR_INVALID_ARGUMENT, "unknown option %s", key);
+    if (hipSetDevice(ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+      return cuking_fail(CUKING_ERR_DEVICE, "device wait failed");
+    unsigned long long total = 0;
+    for (auto &e : ctx->filter_scratch) {
+      unsigned long long v = 0;
+      if (hipMemcpy(&v, e.base + filter_scratch_layout(e.tiles).totals + (size_t)word * 8, 8,
+                    hipMemcpyDeviceToHost) != hipSuccess)
+        return cuking_fail(CUKING_ERR_DEVICE, "reading the filter counters failed");
+      total += v;
+    }
+    *value = (int64_t)total;
+  }
+  else if (strcmp(key, "filter_step_ticks16") == 0) {
+    // Diagnostic (WAITS for the device): the 100 MHz counter's ticks per k-step x 16 as the
+    // tiles of the last launch chunk measured them (rotated tiles, king_filter.hip), averaged
+    // over the XCDs that said so and the context's streams; 0 = nobody did.
+    if (hipSetDevice(ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+      return cuking_fail(CUKING_ERR_DEVICE, "device wait failed");
+    uint64_t sum = 0, count = 0;
+    for (auto &e : ctx->filter_scratch) {
+      uint32_t w[8];
+      if (hipMemcpy(w, e.base + kCtrlStepTicks * 4, sizeof w, hipMemcpyDeviceToHost) != hipSuccess)
+        return cuking_fail(CUKING_ERR_DEVICE, "reading the filter counters failed");
+      for (uint32_t v : w)
+        if (v != 0) {
+          sum += v;
+          ++count;
+        }
+    }
+    *value = count != 0 ? (int64_t)(sum / count) : 0;
   }
   else if (strcmp(key, "workspace_allocations") == 0) *value = (int64_t)ctx->workspace_allocations;
   else if (strcmp(key, "host_syncs") == 0) *value = (int64_t)ctx->host_syncs;

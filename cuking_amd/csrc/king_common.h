@@ -236,6 +236,11 @@ struct TiledArgs {
   // (the tiles of a few rounds have not drifted apart yet).
   uint32_t rotate, rotate_min_steps;
   uint32_t rotate_min_tiles;  // (host side: launches of fewer tiles are not rotated)
+  // Persistent launch of the filter kernel (king_filter.hip king_filter_persistent_kernel):
+  // on entry (host side) 1 = allowed; in a launch != 0: the indices of the one-tile-per-
+  // workgroup grid that the resident workgroups take in turn before the dynamic tail.
+  uint32_t persist_wgs;
+  uint32_t persist_min_tiles;  // (host side: shorter launches go out one workgroup per tile)
   // one flag per tile of the launch chunk, directly behind the chunk's control words
   // (filter_ctrl + kCtrlChunkBytes: one memset clears both in front of a chunk)
   uint8_t *tile_done;
@@ -396,7 +401,9 @@ constexpr uint32_t kCtrlCand = 0, kCtrlDense = 1, kCtrlDyn = 2, kCtrlFinished = 
 // workgroup's turn on the XCD) mod kPosSlots at its segment ends, a new tile joins the most
 // advanced of them.
 constexpr uint32_t kCtrlStepTicks = 8, kCtrlPos = 16, kPosSlots = 16;
-constexpr size_t kCtrlChunkBytes = 64 + 8 * kPosSlots * 8;
+// ... and behind the slots one ticket counter per XCD (persistent launch).
+constexpr uint32_t kCtrlTickets = kCtrlPos + 8 * kPosSlots * 2;
+constexpr size_t kCtrlChunkBytes = (kCtrlTickets + 16) * 4;
 constexpr uint32_t kTotalCand = 0, kTotalDense = 1, kTotalEarly = 2, kTotalRotated = 3;
 constexpr uint32_t kNumTotals = 4;
 __host__ __device__ inline const uint32_t *plane_check_steps(const uint4 *planes,

@@ -208,6 +208,9 @@ __device__ __forceinline__ v8i tfrag(const uint4 w, uint32_t mask) {
 #ifndef CUKING_FILTER_ABLATE
 #define CUKING_FILTER_ABLATE 0
 #endif
+#ifndef CUKING_FILTER_TIMING
+#define CUKING_FILTER_TIMING 0
+#endif
 
 __device__ __forceinline__ uint4 shl2(const uint4 w) {
   return make_uint4(w.x << 2, w.y << 2, w.z << 2, w.w << 2);
@@ -224,20 +227,48 @@ __device__ __forceinline__ uint4 shl2(const uint4 w) {
                : "s"(DST), "v"(lane16), "s"(SRC)                               \
                : "memory", "m0")
 
-__global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) {
-  extern __shared__ uint4 lds[];  // [kStages][side][k-half][unit][256]
+// One tile (or one piece of the k range of a tile) of the launch: what workgroup `wg` of a
+// grid of one workgroup per tile does.  Returns 1 when there was nothing left to take (the
+// dynamic tail is through: uniform, before anything else), 0 otherwise -- wavefronts return
+// from the epilogue one by one.  lds: [kStages][side][k-half][unit][256].
+__device__ __forceinline__ int filter_tile(const TiledArgs &a, const uint32_t wg, uint4 *const lds) {
 
-  uint32_t bid = blockIdx.x;
+#if CUKING_FILTER_TIMING
+  // Timing build (tools/tile_gaps.sh): how long a CU waits for its next workgroup, and how
+  // long a workgroup takes to its first request.  Totals 8 .. 11 (100 MHz ticks, summed by
+  // thread 0): gaps between a workgroup's exit at the check point and the entry of the next
+  // workgroup on the same CU, their number, entry -> first request, their number.  The
+  // table of last exits per CU sits in the (idle) slabs of the remainder pieces.
+  const uint32_t t_entry = (uint32_t)__builtin_amdgcn_s_memrealtime();
+  uint32_t cu_key;
+  {
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    cu_key = ((xcc & 15u) << 8) | ((hw >> 8) & 255u);  // XCC | SE, SH, CU
+  }
+  uint32_t *const cu_last_exit = reinterpret_cast<uint32_t *>(a.fsplit_slabs);
+  if (threadIdx.x == 0 && cu_last_exit != nullptr && a.tile_done != nullptr) {
+    const uint32_t last = __hip_atomic_load(cu_last_exit + cu_key, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+    if (last != 0) {
+      __hip_atomic_fetch_add(a.filter_totals + 8, (unsigned long long)(t_entry - last),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(a.filter_totals + 9, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+#endif
+  uint32_t bid = wg;
   // Remainder of a short launch (king_common.h, fsplit_*): piece `part` of the k
   // range of one of the launch's last tiles.
-  const bool split = a.fsplit_parts != 0 && blockIdx.x >= a.fsplit_first;
+  const bool split = a.fsplit_parts != 0 && wg >= a.fsplit_first;
   uint32_t part = 0, piece = 0;
   if (split) {
-    piece = blockIdx.x - a.fsplit_first;
+    piece = wg - a.fsplit_first;
     part = __builtin_amdgcn_readfirstlane(piece % a.fsplit_parts);
     bid = a.fsplit_tile0 + piece / a.fsplit_parts;
   } else
-  if (a.dyn_tiles != 0 && blockIdx.x >= a.launch_tiles) {
+  if (a.dyn_tiles != 0 && wg >= a.launch_tiles) {
     // dynamic tail (king_common.h): the next of the launch's last dyn_tiles tiles
     // nobody has taken yet -- the XCDs run at rates a few percent apart, and an
     // XCD that gets through its static share early takes more of these.  (The
@@ -249,17 +280,17 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
     __syncthreads();
     const uint32_t t = __builtin_amdgcn_readfirstlane(*slot);
     __syncthreads();  // the word is stage memory from here on
-    if (t >= a.dyn_tiles) return;  // uniform
+    if (t >= a.dyn_tiles) return 1;  // uniform: nothing left
     bid = a.launch_tiles + t;
   } else if (a.xcd_chunk == 1) {
     // patches of 32 consecutive tiles dealt round-robin to the XCDs (king_common.h)
     const uint32_t x = bid & 7, j = bid >> 3;
     bid = (((j >> 5) * 8 + x) << 5) + (j & 31);
-    if (bid >= a.launch_tiles) return;  // padding (uniform)
+    if (bid >= a.launch_tiles) return 0;  // padding (uniform)
   }
   bid = __builtin_amdgcn_readfirstlane(bid);
   uint32_t tr, tc;
-  if (!decode_tile_space(a, a.tile_begin + bid, &tr, &tc)) return;  // uniform
+  if (!decode_tile_space(a, a.tile_begin + bid, &tr, &tc)) return 0;  // uniform
   tr = __builtin_amdgcn_readfirstlane(tr);
   tc = __builtin_amdgcn_readfirstlane(tc);
 
@@ -310,7 +341,7 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
     // round-robin by their index.  Every slot says where one of them was and when; brought
     // forward to now by the measured k-step time, the most advanced one counts.
     if (a.rotate == 1 && threadIdx.x < kPosSlots) {
-      const uint32_t x = blockIdx.x & 7;
+      const uint32_t x = wg & 7;
       const unsigned long long said = __hip_atomic_load(
           reinterpret_cast<const unsigned long long *>(a.filter_ctrl + kCtrlPos) + x * kPosSlots +
               threadIdx.x,
@@ -330,7 +361,7 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
       for (uint32_t k = 0; k < kPosSlots; ++k) xcd_pos = max(xcd_pos, verdict[1 + k]);
     }
     __syncthreads();  // the words are stage memory from here on
-    if (give_up) return;  // uniform across the workgroup; tile_done stays 0
+    if (give_up) return 0;  // uniform across the workgroup; tile_done stays 0
   }
   xcd_pos = __builtin_amdgcn_readfirstlane(xcd_pos);
   const uint32_t g = lane >> 5;                  // k-half of the MFMA operand
@@ -664,10 +695,18 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
   // here makes the compiler treat the segment loop as divergent)
   unsigned long long *const pos_word =
       reinterpret_cast<unsigned long long *>(a.filter_ctrl + kCtrlPos) +
-      (blockIdx.x & 7) * kPosSlots + ((blockIdx.x >> 3) & (kPosSlots - 1));
-  uint32_t *const ticks_word = a.filter_ctrl + kCtrlStepTicks + (blockIdx.x & 7);
+      (wg & 7) * kPosSlots + ((wg >> 3) & (kPosSlots - 1));
+  uint32_t *const ticks_word = a.filter_ctrl + kCtrlStepTicks + (wg & 7);
   // (the first request of the tile goes out about now)
   const uint32_t t_start = a.rotate == 1 ? (uint32_t)__builtin_amdgcn_s_memrealtime() : 0u;
+#if CUKING_FILTER_TIMING
+  if (threadIdx.x == 0 && a.tile_done != nullptr && !split) {
+    __hip_atomic_fetch_add(a.filter_totals + 10,
+                           (unsigned long long)((uint32_t)__builtin_amdgcn_s_memrealtime() - t_entry),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(a.filter_totals + 11, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#endif
 #define F_PUBLISH(STEPS)                                                       \
   if (a.rotate == 1 && wave == 0) {                                            \
     const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memrealtime();          \
@@ -868,9 +907,14 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
         __hip_atomic_fetch_add(
             a.filter_totals + kTotalEarly, 1ull,
             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if CUKING_FILTER_TIMING
+        if (cu_last_exit != nullptr)
+          __hip_atomic_store(cu_last_exit + cu_key, (uint32_t)__builtin_amdgcn_s_memrealtime() | 1u,
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
       }
     }
-    return;
+    return 0;
   }
 
   // This tile runs to its end here: the fallback launch has nothing to do for it.
@@ -921,7 +965,7 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
     __syncthreads();
     const bool last = *flag != 0;
     __syncthreads();  // (the flag word becomes the epilogue's scratch)
-    if (!last) return;
+    if (!last) return 0;
     const uint32_t first_piece = piece - part;
     for (uint32_t p = 0; p < a.fsplit_parts; ++p) {
       if (p == part) continue;
@@ -950,7 +994,7 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) sum += acc[bi][bj][r];
     if (sum == -1.f) a.results[0].kin = sum;  // never true, keeps the sums alive
-    return;
+    return 0;
   }
 
   // --- epilogue: the bound, per pair.  C layout of the 32 x 32 MFMA: column =
@@ -999,7 +1043,7 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
     if (__ballot(best > 0.f) == 0) {  // wave-uniform
       if (lane == 0)
         __hip_atomic_fetch_add(a.filter_ctrl + kCtrlFinished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return;
+      return 0;
     }
   }
   if (lane == 0)
@@ -1074,6 +1118,49 @@ __global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) 
         break;
       }
     }
+  }
+  return 0;
+}
+
+__global__ __launch_bounds__(256, 1) void king_filter_kernel(const TiledArgs a) {
+  extern __shared__ uint4 lds[];
+  (void)filter_tile(a, blockIdx.x, lds);
+}
+
+// The same launch from ONE workgroup per CU that takes tile after tile (king_common.h
+// persist_wgs; option "filter_persistent", OFF by default).  A CU waits 32 us of a 430 us tile
+// for the dispatcher between two workgroups of the one-tile-per-workgroup grid
+// (tools/tile_gaps.sh: exit at the check point -> entry of the next workgroup on the same
+// CU; 160 KiB of LDS and 512 registers per workgroup) -- and yet this kernel, which does not
+// wait, runs configs[2] in 135.9-136.0 ms against 134.3-134.4 (same box, interleaved): the chip
+// is power-bound under the matrix pipes, and what an idle CU does not draw the others clock
+// on.  Kept as a measured alternative and for the tests.  The workgroups of XCD x (workgroups go to the XCDs round-robin by their index)
+// take the indices x, 8 + x, 16 + x, ... of the one-tile-per-workgroup grid through a ticket
+// counter of the XCD -- the same tiles in the same order as the dispatcher would hand them
+// out --, then the dynamic tail's tiles through its counter like everybody else.
+__global__ __launch_bounds__(256, 1) void king_filter_persistent_kernel(const TiledArgs a) {
+  extern __shared__ uint4 lds[];
+  const uint32_t x = blockIdx.x & 7;
+  bool tail = false;  // (uniform)
+  for (;;) {
+    uint32_t wg = a.launch_tiles + x;  // (an index of the dynamic tail)
+    if (!tail) {
+      uint32_t *slot = reinterpret_cast<uint32_t *>(lds);
+      if (threadIdx.x == 0)
+        *slot = __hip_atomic_fetch_add(a.filter_ctrl + kCtrlTickets + x, 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const uint32_t j = __builtin_amdgcn_readfirstlane(*slot);
+      __syncthreads();  // the word is stage memory from here on
+      if (j * 8 + x < a.persist_wgs) {
+        wg = j * 8 + x;
+      } else {
+        if (a.dyn_tiles == 0) break;
+        tail = true;
+      }
+    }
+    if (filter_tile(a, wg, lds) != 0) break;
+    __syncthreads();  // every wavefront is through with the tile's stage memory
   }
 }
 
@@ -1182,6 +1269,9 @@ hipError_t launch_filter(const TiledArgs &args, uint64_t num_tiles, hipStream_t 
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)kFilterLdsBytes);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(king_filter_persistent_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFilterLdsBytes);
+    if (e != hipSuccess) return e;
     attr_set.mark();
   }
   uint64_t cap = max_blocks_per_launch(256);
@@ -1197,6 +1287,12 @@ hipError_t launch_filter(const TiledArgs &args, uint64_t num_tiles, hipStream_t 
     const bool checks = args.tile_done != nullptr;
     hipError_t e = hipMemsetAsync(args.filter_ctrl, 0, kCtrlChunkBytes + (checks ? n : 0), stream);
     if (e != hipSuccess) return e;
+#if CUKING_FILTER_TIMING
+    if (args.fsplit_slabs != nullptr) {  // (the timing build's table of last exits per CU)
+      e = hipMemsetAsync(args.fsplit_slabs, 0, 4096 * sizeof(uint32_t), stream);
+      if (e != hipSuccess) return e;
+    }
+#endif
     TiledArgs a = args;
     a.tile_begin = args.tile_begin + done;
     a.quad = 0;
@@ -1260,7 +1356,15 @@ hipError_t launch_filter(const TiledArgs &args, uint64_t num_tiles, hipStream_t 
       e = hipMemsetAsync(args.tile_done + n_whole, 1, rest, stream);
       if (e != hipSuccess) return e;
     }
-    king_filter_kernel<<<dim3((uint32_t)grid), dim3(256), kFilterLdsBytes, stream>>>(a);
+    // On request ("filter_persistent"), launches of many rounds without remainder pieces:
+    // one resident workgroup per CU takes the grid's indices in turn.
+    a.persist_wgs = 0;
+    if (args.persist_wgs != 0 && rest == 0 && n >= args.persist_min_tiles) {
+      a.persist_wgs = (uint32_t)(a.dyn_tiles != 0 ? a.launch_tiles : grid);
+      king_filter_persistent_kernel<<<dim3(wgs), dim3(256), kFilterLdsBytes, stream>>>(a);
+    } else {
+      king_filter_kernel<<<dim3((uint32_t)grid), dim3(256), kFilterLdsBytes, stream>>>(a);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     king_refine_kernel<<<dim3(wgs * 4), dim3(256), 0, stream>>>(a);

@@ -116,6 +116,7 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
         emit = int(rng.choice([64, 64, 0, 1, 255]))    # live pairs a tile hands over at the check
         # rotated tiles: as shipped (joins the XCD's position) / off / a phase per tile / one phase
         rot = int(rng.choice([1, 0, 2, 2, 3 + int(rng.integers(0, 64))]))
+        pers = int(rng.integers(0, 2))       # one resident workgroup per CU takes tile after tile
         if case < first_case:
             continue
         tag = dict(fuzzer="run_general", seed=seed, case=case, n=n, m=m, split_factor=k,
@@ -124,7 +125,8 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
                    filter_quadrant_cap=qcap, filter_cand_cap=ccap, filter_split_min_steps=smin,
                    filter_check0=chk0, filter_check1=chk1, filter_check_min_steps=4,
                    filter_sort=srt, filter_lazy_codes=lazy, filter_check_emit=emit,
-                   filter_rotate=rot, filter_rotate_min_steps=4)
+                   filter_rotate=rot, filter_rotate_min_steps=4, filter_persistent=pers,
+                   filter_persistent_min_tiles=0)
         osm = pyoracle.submatrix(n, k, shard)
         bits = pyoracle.bitset_from_genotypes(geno, osm)
         exp, _, _ = pyoracle.compute(osm, bits, thr, threads=8)
@@ -144,6 +146,8 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
         ctx.set_option("filter_rotate", rot)
         ctx.set_option("filter_rotate_min_steps", 4)
         ctx.set_option("filter_rotate_min_tiles", 0)
+        ctx.set_option("filter_persistent", pers)
+        ctx.set_option("filter_persistent_min_tiles", 0)
         ctx.set_option("filter_check_min_steps", 4)
         ctx.set_option("filter_sort", srt)
         ctx.set_option("filter_lazy_codes", lazy)
@@ -185,6 +189,8 @@ def run_general(ctx, seed: int, cases: int, first_case: int = 0, log=None) -> in
     ctx.set_option("filter_rotate", 1)
     ctx.set_option("filter_rotate_min_steps", 128)
     ctx.set_option("filter_rotate_min_tiles", 2048)
+    ctx.set_option("filter_persistent", 0)
+    ctx.set_option("filter_persistent_min_tiles", 2048)
     ctx.set_option("filter_check_min_steps", 64)
     ctx.set_option("filter_sort", 1)
     ctx.set_option("filter_lazy_codes", 1)

@@ -1262,7 +1262,8 @@ def test_filter_check_points_inside_the_k_loop(ctx, oracle, missing):
     sub = np.ascontiguousarray(bits[idx])
     d_sub = ctx.upload_bitset(sub)
     defaults = {"filter_check0": 1, "filter_check1": 1, "filter_check_emit": 64,
-                "filter_rotate": 1, "filter_split_min_steps": 8,
+                "filter_rotate": 1, "filter_persistent": 0, "filter_persistent_min_tiles": 2048,
+                "filter_split_min_steps": 8,
                 "max_launch_blocks": 0, "filter_quadrant_cap": 384, "split_wgs": 256}
     ctx.set_option("filter_check_min_steps", 4)
     ctx.set_option("filter_rotate_min_steps", 4)
@@ -1289,8 +1290,12 @@ def test_filter_check_points_inside_the_k_loop(ctx, oracle, missing):
                       {"filter_rotate": 2, "filter_check0": 2, "split_wgs": 0},
                       {"filter_rotate": 2, "filter_check0": 2, "filter_check1": 0, "split_wgs": 0},
                       {"filter_rotate": 2, "filter_check0": 2, "filter_quadrant_cap": 0, "split_wgs": 0}]
+            # ... and the persistent launch (one resident workgroup per CU takes tile after
+            # tile): every second case above once more that way
+            cases += [{**c, "filter_persistent": 1, "filter_persistent_min_tiles": 0}
+                      for c in cases[3::2] if c.get("split_wgs") == 0]
             cases += [{"filter_rotate": 3 + ph, "filter_check0": c0, "filter_check1": 2 + k,
-                       "split_wgs": 0}
+                       "split_wgs": 0, "filter_persistent": ph & 1, "filter_persistent_min_tiles": 0}
                       for ph, c0, k in ((1, 0, 3), (9, 2, 1), (13, 0, 7), (31, 2, 4), (40, 0, 2),
                                         (57, 2, 5), (63, 0, 3), (63, 2, 7))]
             for opts in cases:
@@ -1358,8 +1363,10 @@ def test_filter_rotated_tiles_join_the_position_of_their_xcd(ctx, oracle):
     ctx.set_option("filter_rotate_min_tiles", 0)
     ctx.set_option("split_wgs", 0)             # whole tiles only (remainder pieces never rotate)
     try:
-        for rotate in (1, 0, 1):
+        for rotate, persistent in ((1, 0), (0, 0), (1, 1), (0, 1), (1, 1)):
             ctx.set_option("filter_rotate", rotate)
+            ctx.set_option("filter_persistent", persistent)
+            ctx.set_option("filter_persistent_min_tiles", 0)
             r0 = ctx.get_option("filter_rotated_tiles")
             x0 = ctx.get_option("filter_early_exits")
             got = ctx.run(sm, bits.shape[1], d_bits, thr, max_results=1 << 20)
@@ -1377,6 +1384,7 @@ def test_filter_rotated_tiles_join_the_position_of_their_xcd(ctx, oracle):
     finally:
         for k, v in (("filter_check_min_steps", 64), ("filter_rotate_min_steps", 128),
                      ("filter_rotate_min_tiles", 2048), ("filter_rotate", 1), ("split_wgs", 256),
+                     ("filter_persistent", 0), ("filter_persistent_min_tiles", 2048),
                      ("counts_mode", -1)):
             ctx.set_option(k, v)
 
