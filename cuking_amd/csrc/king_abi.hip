@@ -431,7 +431,8 @@ cuking_status filter_scratch_for(cuking_ctx *ctx, hipStream_t stream, const Plan
   a->fsplit_first = ctx->filter_split_min_steps;  // (on entry: launch_filter)
   a->fsplit_slabs = ctx->split_wgs != 0 ? reinterpret_cast<float4 *>(base + l.slabs) : nullptr;
   a->check0 = (uint32_t)ctx->filter_check0;  // (switches on entry: launch_filter)
-  a->check1 = (uint32_t)ctx->filter_check1 | ((uint32_t)ctx->filter_check_emit << 8);
+  a->check1 = (uint32_t)ctx->filter_check1 | ((uint32_t)ctx->filter_check_emit << 8) |
+              (ctx->filter_check0 != 0 ? 1u << 16 : 0u);
   a->rotate = (uint32_t)ctx->filter_rotate;
   a->rotate_min_steps = ctx->filter_rotate_min_steps;
   a->rotate_min_tiles = ctx->filter_rotate_min_tiles;

@@ -226,7 +226,9 @@ struct TiledArgs {
   const unsigned long long *cohort_sums;
   // switches (check1, bits 0-7: 0 off, 1 automatic, 2 + k: entry k forced; bits 8-15: live
   // pairs per quadrant up to which a tile that fails the rigorous check hands them to the
-  // candidate list and leaves anyway, kCheckEmitCap unless a test says otherwise)
+  // candidate list and leaves anyway, kCheckEmitCap unless a test says otherwise; bit 16:
+  // the tiles may give up at once where the cohort's sums say the bound lets every pair
+  // through -- the forecast's switch, whatever the launch's length)
   uint32_t check0, check1;
   // Rotated tiles (king_filter.hip): 0 every tile starts at its first k-step; 1 a whole tile
   // with check points starts at the phase boundary the other tiles of its XCD are at

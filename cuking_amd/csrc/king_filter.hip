@@ -321,6 +321,26 @@ __device__ __forceinline__ int filter_tile(const TiledArgs &a, const uint32_t wg
     if (threadIdx.x == 0) {
       uint32_t leave = __hip_atomic_load(a.filter_ctrl + kCtrlAllLeave, __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_AGENT);
+      // The cohort's own verdict first: where the bound's level for unrelated pairs (from the
+      // cohort's mean missing and het rates, as for the check points below) lies four
+      // standard deviations above the threshold, it lets every pair through, whatever the
+      // tile -- the first tiles need not find that out by computing their product.
+      if (leave == 0 && a.cohort_sums != nullptr && a.check_steps != nullptr) {
+        const float ns = (float)a.cohort_sums[0], nm = (float)a.cohort_sums[1],
+                    nh = (float)a.cohort_sums[2];
+        if (ns > 0.f && nh > 0.f) {
+          const float sites = 32.f * (float)a.geo.k_words;
+          const float m = nm / (ns * sites), h = nh / (ns * sites);
+          if (m * (1.f + m / (2.f * h * (1.f - m))) - 4.f * rsqrtf(sites) > a.kin_threshold &&
+              (a.check1 >> 16) != 0) {
+            leave = 1;
+            __hip_atomic_store(a.filter_ctrl + kCtrlAllLeave, 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.filter_ctrl + kCtrlGate, 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
       if (leave == 0) {
         const uint32_t dense_so_far =
             __hip_atomic_load(a.filter_ctrl + kCtrlDense, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
@@ -361,7 +381,13 @@ __device__ __forceinline__ int filter_tile(const TiledArgs &a, const uint32_t wg
       for (uint32_t k = 0; k < kPosSlots; ++k) xcd_pos = max(xcd_pos, verdict[1 + k]);
     }
     __syncthreads();  // the words are stage memory from here on
-    if (give_up) return 0;  // uniform across the workgroup; tile_done stays 0
+    if (give_up) {  // uniform across the workgroup; tile_done stays 0
+      // (its quadrants count as handed over: "filter_dense_quadrants")
+      if (threadIdx.x == 0)
+        __hip_atomic_fetch_add(a.filter_totals + kTotalDense, 4ull, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+      return 0;
+    }
   }
   xcd_pos = __builtin_amdgcn_readfirstlane(xcd_pos);
   const uint32_t g = lane >> 5;                  // k-half of the MFMA operand
@@ -823,7 +849,7 @@ __device__ __forceinline__ int filter_tile(const TiledArgs &a, const uint32_t wg
       ck_cols[threadIdx.x] = make_float2(prefix_u_of(share, ic, sc.x), scale * fmaf(t, sc.y, 8.f));
     }
     __syncthreads();
-    const uint32_t emit_cap = a.check1 >> 8;  // (uniform; king_common.h check1)
+    const uint32_t emit_cap = (a.check1 >> 8) & 0xFFu;  // (uniform; king_common.h check1)
     uint32_t cnt = 0;  // pairs of this lane still under the bound
     {
       float2 cc[4];
