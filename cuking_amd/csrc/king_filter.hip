@@ -37,11 +37,21 @@
 // Same records as every other variant, whatever the data: the bound only
 // decides WHO computes a pair exactly.
 //
+// Round 4, all inside filter_tile() below: check points inside the k loop (a tile
+// none of whose pairs can still become a candidate leaves, and so does one that
+// holds a few, handing them to the candidate list: "Check points"); rotated tiles
+// (a tile starts its k loop where the tiles of its XCD are and wraps around, so
+// that they share their operands through the XCD's L2: "Rotated tiles"); tiles
+// that give up leave for a gated launch of the four-product kernel instead of
+// appending to a list; king_filter_persistent_kernel, the same launch from one
+// resident workgroup per CU (measured, off by default).
+//
 // Workgroup = 256 x 256 pairs, 4 wavefronts of 128 x 128 = 4 x 4 MFMA blocks (256
 // accumulator registers), k-step = 256 sites = 4 slices of 64, 5 LDS stages of
 // 32 KiB by LDS-DMA.  Per k-step and wavefront: 64 MFMAs, 16 ds_read_b128, 192
 // VALU (128 v_and + 64 v_lshl), 8 requests of 1 KiB.  DESIGN.md 4.0 has the
-// measurements; profiles/r03_ablation.txt and r03_filter_curve.txt the raw numbers.
+// measurements; profiles/r03_ablation.txt, r03_filter_curve.txt, r04_l2_probe.txt and
+// r04_tile_gaps.txt the raw numbers.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 
